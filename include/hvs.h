@@ -1,0 +1,109 @@
+/*
+ * hvs.h -- C ABI of the MI355X-native filtered brute-force k-NN engine (libhvs.so).
+ *
+ * Drop-in boundary for ONE path of atalantus/Project---Hybrid-Vector-Search-Queries:
+ * the `vec_query` seam every engine header of the reference defines
+ *     void vec_query(vector<vector<float>>& nodes, vector<vector<float>>& queries,
+ *                    float sample_proportion, vector<vector<uint32_t>>& knn_results);
+ * (reference include/optimized_parallel.hpp:61-62, include/optimized.hpp:54-55,
+ * include/baseline.hpp:68-69; called once from src/test.cpp:85) together with the
+ * binary formats of include/io.h (D rows = 102 f32 [C,T,x0..x99], Q rows = 104 f32
+ * [type,v,l,r,x0..x99], output.bin = nq x 100 uint32 ids in ascending distance).
+ *
+ * std::vector cannot cross a C ABI, so the boundary takes flat row-major buffers; the
+ * header-only shim include/hvs_vec_query.hpp restores the exact C++ signature.
+ *
+ * Conventions: plain pointers and sizes, no exceptions, int status (0 = ok, negative =
+ * HVS_E*), one hvs_ctx is used from one thread at a time (the reference has a single
+ * caller, src/test.cpp:85), all work of a context runs on the context's own HIP stream
+ * on one GPU.  k = 100 and dim = 100 are compile-time constants like the reference's
+ * KNN_LIMIT / VEC_DIM (include/optimized_impl.h:26-28).
+ */
+#ifndef HVS_H
+#define HVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVS_OK 0
+#define HVS_EINVAL (-1)  /* bad argument (NULL, n < 100, nq range ...) */
+#define HVS_ENOMEM (-2)  /* host or device allocation failed */
+#define HVS_EHIP (-3)    /* a HIP runtime call failed; see hvs_last_error */
+#define HVS_ESTATE (-4)  /* call order: no data / no queries / no results loaded */
+
+typedef struct hvs_ctx hvs_ctx;
+
+/* Engines.  HVS_ENGINE_AUTO picks the fastest exact engine for the loaded data. */
+#define HVS_ENGINE_AUTO 0
+#define HVS_ENGINE_EXACT_SCAN 1 /* FP32 exact-order scan of every candidate row (VALU)       */
+#define HVS_ENGINE_MFMA_FILTER 2 /* BF16 MFMA bound filter + exact-order re-scoring            */
+
+typedef struct hvs_timing {
+    double query_ms;      /* whole vec_query-equivalent region on the device stream (HIP events)   */
+    double main_kernel_ms;/* sum of the dominant kernel's launches inside that region               */
+    uint32_t main_kernel_launches;
+    uint32_t nq;          /* queries answered                                                       */
+    uint64_t pairs;       /* sum over queries of rows in [0,sn) passing the predicate (P of SURVEY 8d) */
+    uint64_t scanned_pairs;/* (query,row) pairs the dominant kernel actually evaluated              */
+    double load_ms;       /* last hvs_load_data / hvs_gen_data: upload + index build                */
+    uint32_t engine;      /* engine that ran                                                        */
+    uint32_t fallback_queries; /* queries re-run by the exact scan after a filter overflow          */
+} hvs_timing;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* device < 0: use the calling thread's current HIP device. */
+int hvs_create(hvs_ctx **out, int device);
+void hvs_destroy(hvs_ctx *ctx);
+/* Message of the last failing call on this context ("" if none). Valid until the next call. */
+const char *hvs_last_error(const hvs_ctx *ctx);
+/* Library-level message for failures that have no context (hvs_create). */
+const char *hvs_last_global_error(void);
+int hvs_set_engine(hvs_ctx *ctx, int engine);
+
+/* ---- data set D (replaces `nodes`, reference src/test.cpp:71-73 + io.h:111-136) ---------- */
+
+/* rows: host memory, n x 102 f32.  Requires n >= 100 (the reference's padding index n-s
+ * underflows below that, optimized.hpp:125).  Uploads and builds the device-side layout. */
+int hvs_load_data(hvs_ctx *ctx, const float *rows, uint32_t n);
+/* Generate gen-v1 rows (include/hvs_gen.h) directly in HBM. */
+int hvs_gen_data(hvs_ctx *ctx, uint32_t n, uint64_t seed, int profile, uint32_t ncat);
+/* Copy raw rows [row0,row0+nrows) back to the host (n x 102 layout). */
+int hvs_download_data(hvs_ctx *ctx, uint32_t row0, uint32_t nrows, float *out_rows);
+uint32_t hvs_num_rows(const hvs_ctx *ctx);
+
+/* ---- the vec_query seam ------------------------------------------------------------------ */
+
+/*
+ * q_rows: host, nq x 104 f32.  out_ids: host, nq x 100 u32 (output.bin row layout, ascending
+ * distance, canonical tie rule (dist asc, id asc)).  out_dists: host, nq x 100 f32 exact-order
+ * distances of those ids, or NULL.  sample_proportion as in the reference: rows [0, sn) are
+ * searched with sn = uint32(float(sample_proportion) * float(n)) (optimized_parallel.hpp:67);
+ * padding ids come from the end of the full set (n-1, n-2, ...), optimized_parallel.hpp:149-157.
+ */
+int hvs_query(hvs_ctx *ctx, const float *q_rows, uint32_t nq, float sample_proportion, uint32_t *out_ids,
+              float *out_dists);
+
+/* ---- device-resident variant (benchmarks, multi-GPU drivers: inputs already in HBM) ------ */
+
+int hvs_upload_queries(hvs_ctx *ctx, const float *q_rows, uint32_t nq);
+int hvs_gen_queries(hvs_ctx *ctx, uint32_t nq, uint64_t seed, int profile, uint32_t ncat, int force_type,
+                    uint64_t first_row);
+int hvs_download_queries(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float *out_rows);
+/* Answer resident queries [q0, q0+nq); results stay on the device (rows q0..q0+nq of the result
+ * buffer).  Asynchronous on the context stream; hvs_sync waits. */
+int hvs_query_resident(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float sample_proportion);
+int hvs_sync(hvs_ctx *ctx);
+int hvs_download_results(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *out_ids, float *out_dists);
+/* Timing of the last hvs_query / hvs_query_resident (call after hvs_sync). */
+int hvs_last_timing(hvs_ctx *ctx, hvs_timing *out);
+
+const char *hvs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVS_H */

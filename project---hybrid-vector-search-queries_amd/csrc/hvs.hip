@@ -1,0 +1,490 @@
+// hvs.hip -- host side of libhvs.so: context, HBM residency, launch plan, C ABI (include/hvs.h).
+//
+// Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared hvs.hip -o libhvs.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/hvs.h"
+#include "hvs_kernels.h"
+
+namespace {
+
+thread_local std::string g_global_err;
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace
+
+struct hvs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int engine = HVS_ENGINE_AUTO;
+    std::string err;
+
+    // data set, raw rows n x 102 (the io.h layout) resident in HBM
+    float* d_data = nullptr;
+    uint32_t n = 0;
+    double load_ms = 0.0;
+
+    // resident queries + results
+    float* d_q = nullptr;
+    uint32_t nq = 0, nq_cap = 0;
+    uint32_t* d_out_ids = nullptr;
+    float* d_out_dists = nullptr;
+    uint32_t res_cap = 0;
+
+    // workspace of one query batch
+    uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
+    uint32_t *d_qidx = nullptr, *d_qorder = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t batch_cap = 0;
+    uint64_t* d_cand = nullptr;
+    uint32_t* d_cand_cnt = nullptr;
+    size_t cand_lists = 0;
+    unsigned long long* d_counters = nullptr;
+
+    hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;
+    static constexpr int kMaxLaunchEvents = 64;
+    hipEvent_t ev_k0[kMaxLaunchEvents], ev_k1[kMaxLaunchEvents];
+    int n_launch_events = 0;
+    bool timing_valid = false;
+    hvs_timing timing{};
+};
+
+namespace {
+
+constexpr uint32_t kBatch = 65536;  // queries answered per pass over D
+
+int fail(hvs_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HVS_HIP(ctx, call)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? HVS_ENOMEM : HVS_EHIP,                                \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                    \
+    } while (0)
+
+template <typename T>
+int dev_alloc(hvs_ctx* c, T** p, size_t count)
+{
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (count == 0) return HVS_OK;
+    HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return HVS_OK;
+}
+
+// optimized_parallel.hpp:67: const uint32_t sn = uint32_t(sample_proportion * n);  (float product)
+uint32_t sample_rows(float sample_proportion, uint32_t n)
+{
+    const float p = sample_proportion * (float)n;
+    if (!(p > 0.0f)) return 0u;
+    if (p >= 4294967296.0f) return n;
+    const uint32_t sn = (uint32_t)p;
+    return sn > n ? n : sn;
+}
+
+int ensure_results(hvs_ctx* c, uint32_t nq)
+{
+    if (nq <= c->res_cap) return HVS_OK;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_out_ids, (size_t)nq * HVS_KNN))) return rc;
+    if ((rc = dev_alloc(c, &c->d_out_dists, (size_t)nq * HVS_KNN))) return rc;
+    c->res_cap = nq;
+    return HVS_OK;
+}
+
+int ensure_queries(hvs_ctx* c, uint32_t nq)
+{
+    if (nq > c->nq_cap) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->d_q, (size_t)nq * HVS_QCOLS))) return rc;
+        c->nq_cap = nq;
+    }
+    return ensure_results(c, nq);
+}
+
+struct Plan {
+    uint32_t nq_pad, qwaves, nchunks, rows_per_chunk;
+};
+
+Plan make_plan(uint32_t nqb, uint32_t sn)
+{
+    Plan p;
+    p.qwaves = (nqb + 63u) / 64u;
+    p.nq_pad = ((nqb + 255u) / 256u) * 256u;
+    // enough (query-wave x row-chunk) work items to fill 256 CUs x 16 waves, but chunks of >= 2048 rows
+    uint32_t want = (8192u + p.qwaves - 1u) / p.qwaves;
+    uint32_t max_chunks = std::max(1u, sn / 2048u);
+    p.nchunks = std::max(1u, std::min(std::min(want, max_chunks), 64u));
+    p.rows_per_chunk = (sn + p.nchunks - 1u) / p.nchunks;
+    if (p.rows_per_chunk == 0) p.rows_per_chunk = 1;
+    return p;
+}
+
+int ensure_batch_workspace(hvs_ctx* c, uint32_t nqb, const Plan& p)
+{
+    int rc;
+    if (nqb > c->batch_cap) {
+        if ((rc = dev_alloc(c, &c->d_keys, (size_t)nqb))) return rc;
+        if ((rc = dev_alloc(c, &c->d_keys_sorted, (size_t)nqb))) return rc;
+        if ((rc = dev_alloc(c, &c->d_qidx, (size_t)nqb))) return rc;
+        if ((rc = dev_alloc(c, &c->d_qorder, (size_t)nqb))) return rc;
+        size_t tmp = 0;
+        HVS_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
+                                             (size_t)nqb, 0, 64, c->stream));
+        if (tmp > c->sort_tmp_bytes) {
+            if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+            c->d_sort_tmp = nullptr;
+            HVS_HIP(c, hipMalloc(&c->d_sort_tmp, tmp));
+            c->sort_tmp_bytes = tmp;
+        }
+        c->batch_cap = nqb;
+    }
+    const size_t lists = (size_t)p.nq_pad * p.nchunks;
+    if (lists > c->cand_lists) {
+        if ((rc = dev_alloc(c, &c->d_cand, lists * HVS_CAND_CAP))) return rc;
+        if ((rc = dev_alloc(c, &c->d_cand_cnt, lists))) return rc;
+        c->cand_lists = lists;
+    }
+    return HVS_OK;
+}
+
+// One batch [q0, q0+nqb) of resident queries through the exact engine.
+int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
+{
+    const Plan p = make_plan(nqb, sn);
+    int rc = ensure_batch_workspace(c, nqb, p);
+    if (rc) return rc;
+
+    hipLaunchKernelGGL(hvs_k_query_keys, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
+                       c->d_keys, c->d_qidx);
+    size_t tmp = c->sort_tmp_bytes;
+    HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
+                                         (size_t)nqb, 0, 64, c->stream));
+    HVS_HIP(c, hipMemsetAsync(c->d_cand_cnt, 0, (size_t)p.nq_pad * p.nchunks * sizeof(uint32_t), c->stream));
+
+    const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
+    if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+    if (sn > 0) {
+        hipLaunchKernelGGL(hvs_k_scan_exact, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream, c->d_data,
+                           c->d_q, c->d_qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
+                           c->d_counters);
+    }
+    if (ev >= 0) {
+        HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
+        c->n_launch_events++;
+    }
+    hipLaunchKernelGGL(hvs_k_select, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                       c->d_qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+    HVS_HIP(c, hipGetLastError());
+    return HVS_OK;
+}
+
+int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
+{
+    if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
+    if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
+    HVS_HIP(c, hipSetDevice(c->device));
+    const uint32_t sn = sample_rows(sample_proportion, c->n);
+    c->timing_valid = false;
+    c->n_launch_events = 0;
+    HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
+    for (uint32_t off = 0; off < nq; off += kBatch) {
+        const uint32_t nqb = std::min(kBatch, nq - off);
+        int rc = run_batch_exact(c, q0 + off, nqb, sn);
+        if (rc) return rc;
+    }
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    c->timing = hvs_timing{};
+    c->timing.nq = nq;
+    c->timing.engine = HVS_ENGINE_EXACT_SCAN;
+    c->timing.load_ms = c->load_ms;
+    c->timing_valid = true;
+    return HVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hvs_version(void) { return "hvs-mi355x 0.1 (gfx950)"; }
+
+const char* hvs_last_global_error(void) { return g_global_err.c_str(); }
+
+int hvs_create(hvs_ctx** out, int device)
+{
+    if (!out) {
+        g_global_err = "hvs_create: out is NULL";
+        return HVS_EINVAL;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_global_err = std::string("hvs_create: no HIP device available (") + hipGetErrorString(e) +
+                       "); this library has no CPU fallback";
+        return HVS_EHIP;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) {
+        g_global_err = "hvs_create: device index out of range";
+        return HVS_EINVAL;
+    }
+    hvs_ctx* c = new (std::nothrow) hvs_ctx();
+    if (!c) {
+        g_global_err = "hvs_create: out of host memory";
+        return HVS_ENOMEM;
+    }
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_global_err = std::string("hvs_create: ") + what + ": " + hipGetErrorString(err);
+        hvs_destroy(c);
+        return HVS_EHIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev_q0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_q1)) != hipSuccess) return bail("hipEventCreate", e);
+    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
+        c->ev_k0[i] = c->ev_k1[i] = nullptr;
+    }
+    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
+        if ((e = hipEventCreate(&c->ev_k0[i])) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&c->ev_k1[i])) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 4 * sizeof(unsigned long long))) != hipSuccess)
+        return bail("hipMalloc", e);
+    *out = c;
+    return HVS_OK;
+}
+
+void hvs_destroy(hvs_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_data, c->d_q,      c->d_out_ids,  c->d_out_dists, c->d_keys,    c->d_keys_sorted,
+                    c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->ev_q0) (void)hipEventDestroy(c->ev_q0);
+    if (c->ev_q1) (void)hipEventDestroy(c->ev_q1);
+    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
+        if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
+        if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hvs_last_error(const hvs_ctx* c) { return c ? c->err.c_str() : "hvs: NULL context"; }
+
+int hvs_set_engine(hvs_ctx* c, int engine)
+{
+    if (!c) return HVS_EINVAL;
+    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN)
+        return fail(c, HVS_EINVAL, "hvs_set_engine: engine not available in this build");
+    c->engine = engine;
+    return HVS_OK;
+}
+
+uint32_t hvs_num_rows(const hvs_ctx* c) { return c ? c->n : 0u; }
+
+static int begin_data(hvs_ctx* c, uint32_t n)
+{
+    if (n < HVS_KNN)
+        return fail(c, HVS_EINVAL,
+                    "data set needs at least 100 rows (the reference pads results with rows n-1, n-2, ...)");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->n = 0;
+    return dev_alloc(c, &c->d_data, (size_t)n * HVS_DCOLS);
+}
+
+int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+{
+    if (!c) return HVS_EINVAL;
+    if (!rows) return fail(c, HVS_EINVAL, "hvs_load_data: rows is NULL");
+    int rc = begin_data(c, n);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
+    HVS_HIP(c, hipMemcpyAsync(c->d_data, rows, (size_t)n * HVS_DCOLS * sizeof(float), hipMemcpyHostToDevice,
+                              c->stream));
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->load_ms = ms;
+    c->n = n;
+    return HVS_OK;
+}
+
+int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
+{
+    if (!c) return HVS_EINVAL;
+    if (ncat == 0) return fail(c, HVS_EINVAL, "hvs_gen_data: ncat must be > 0");
+    int rc = begin_data(c, n);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
+    hipLaunchKernelGGL(hvs_k_gen_data, dim3(256 * 8), dim3(256), 0, c->stream, c->d_data, (uint64_t)n * HVS_DCOLS,
+                       seed, profile, ncat);
+    HVS_HIP(c, hipGetLastError());
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->load_ms = ms;
+    c->n = n;
+    return HVS_OK;
+}
+
+int hvs_download_data(hvs_ctx* c, uint32_t row0, uint32_t nrows, float* out_rows)
+{
+    if (!c) return HVS_EINVAL;
+    if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded");
+    if (!out_rows || (uint64_t)row0 + nrows > c->n) return fail(c, HVS_EINVAL, "hvs_download_data: bad range");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipMemcpyAsync(out_rows, c->d_data + (size_t)row0 * HVS_DCOLS, (size_t)nrows * HVS_DCOLS * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+int hvs_upload_queries(hvs_ctx* c, const float* q_rows, uint32_t nq)
+{
+    if (!c) return HVS_EINVAL;
+    if (!q_rows && nq) return fail(c, HVS_EINVAL, "hvs_upload_queries: q_rows is NULL");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = 0;
+    int rc = ensure_queries(c, nq);
+    if (rc) return rc;
+    if (nq)
+        HVS_HIP(c, hipMemcpyAsync(c->d_q, q_rows, (size_t)nq * HVS_QCOLS * sizeof(float), hipMemcpyHostToDevice,
+                                  c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = nq;
+    return HVS_OK;
+}
+
+int hvs_gen_queries(hvs_ctx* c, uint32_t nq, uint64_t seed, int profile, uint32_t ncat, int force_type,
+                    uint64_t first_row)
+{
+    if (!c) return HVS_EINVAL;
+    if (ncat == 0 || force_type > 3) return fail(c, HVS_EINVAL, "hvs_gen_queries: bad ncat / force_type");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = 0;
+    int rc = ensure_queries(c, nq);
+    if (rc) return rc;
+    if (nq) {
+        hipLaunchKernelGGL(hvs_k_gen_queries, dim3(256 * 4), dim3(256), 0, c->stream, c->d_q, (uint64_t)nq * HVS_QCOLS,
+                           seed, profile, ncat, force_type, first_row);
+        HVS_HIP(c, hipGetLastError());
+    }
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = nq;
+    return HVS_OK;
+}
+
+int hvs_download_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float* out_rows)
+{
+    if (!c) return HVS_EINVAL;
+    if (!out_rows || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_queries: bad range");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipMemcpyAsync(out_rows, c->d_q + (size_t)q0 * HVS_QCOLS, (size_t)nq * HVS_QCOLS * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+int hvs_query_resident(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
+{
+    if (!c) return HVS_EINVAL;
+    return run_queries(c, q0, nq, sample_proportion);
+}
+
+int hvs_sync(hvs_ctx* c)
+{
+    if (!c) return HVS_EINVAL;
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+int hvs_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_ids, float* out_dists)
+{
+    if (!c) return HVS_EINVAL;
+    if (!out_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_results: bad range");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipMemcpyAsync(out_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    if (out_dists)
+        HVS_HIP(c, hipMemcpyAsync(out_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
+                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids,
+              float* out_dists)
+{
+    if (!c) return HVS_EINVAL;
+    if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
+    if (nq == 0) return HVS_OK;
+    if (!q_rows || !out_ids) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
+    int rc = hvs_upload_queries(c, q_rows, nq);
+    if (rc) return rc;
+    if ((rc = run_queries(c, 0, nq, sample_proportion))) return rc;
+    return hvs_download_results(c, 0, nq, out_ids, out_dists);
+}
+
+int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
+{
+    if (!c || !out) return HVS_EINVAL;
+    if (!c->timing_valid) return fail(c, HVS_ESTATE, "no query has run yet");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipEventSynchronize(c->ev_q1));
+    float ms = 0.f;
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->timing.query_ms = ms;
+    double k = 0.0;
+    for (int i = 0; i < c->n_launch_events; ++i) {
+        HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_k0[i], c->ev_k1[i]));
+        k += ms;
+    }
+    c->timing.main_kernel_ms = k;
+    c->timing.main_kernel_launches = (uint32_t)c->n_launch_events;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HVS_HIP(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    c->timing.pairs = h[0];
+    c->timing.scanned_pairs = h[1];
+    *out = c->timing;
+    return HVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// hvs_device.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Everything here must reproduce the reference's float32 results bit for bit, so this
+// translation unit is built with -ffp-contract=off (hipcc contracts a + b*b into v_fmac_f32
+// by default; the reference is built without FMA, CMakeLists.txt:8).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HVS_DCOLS 102
+#define HVS_QCOLS 104
+#define HVS_NDIM 100
+#define HVS_KNN 100
+#define HVS_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Query parameters: reference include/optimized_parallel.hpp:93-96
+//   query_type = uint32(q[0]); v = int32(q[1]) (truncation); l = q[2]; r = q[3]
+// `nodes[j][0] == v` compares the row's float with float(v).  Types outside 0..3 (and values
+// whose conversion is undefined behaviour in the reference) match no row: type 4.
+// ---------------------------------------------------------------------------------------------
+struct HvsQParams {
+    uint32_t type;
+    float vf, l, r;
+};
+
+__device__ __forceinline__ HvsQParams hvs_parse_query(const float* __restrict__ q)
+{
+    HvsQParams p;
+    const float t = q[0];
+    p.type = (t >= 0.0f && t < 4.0f) ? (uint32_t)t : 4u;
+    const float v = q[1];
+    if (v > -2147483648.0f && v < 2147483648.0f) {
+        p.vf = (float)(int32_t)v;
+    } else {
+        p.vf = 0.0f;
+        if (p.type == 1u || p.type == 3u) p.type = 4u;
+    }
+    p.l = q[2];
+    p.r = q[3];
+    return p;
+}
+
+// reference include/optimized_parallel.hpp:105-138
+__device__ __forceinline__ bool hvs_row_passes(const HvsQParams& p, float C, float T)
+{
+    const bool ceq = (C == p.vf);
+    const bool tin = (T >= p.l) && (T <= p.r);
+    return p.type == 0u || (p.type == 1u && ceq) || (p.type == 2u && tin) || (p.type == 3u && ceq && tin);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-order squared L2 (reference include/optimized_impl.h:96-125 + hsum :37-47):
+// 8 strided accumulators, 12 full 8-wide steps over dims 0..95, masked tail adding dims
+// 96..99 into accumulators 4..7 (accumulators 0..3 add +0.0f), reduction tree
+// ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)).  sub, mul, add are separate f32 roundings.
+// `d` and `q` are indexable by a compile-time constant (register arrays or pointers).
+// ---------------------------------------------------------------------------------------------
+template <typename DV, typename QV>
+__device__ __forceinline__ float hvs_exact_dist(const DV& d, const QV& q)
+{
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 12; ++b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = d[8 * b + j] - q[8 * b + j];
+            t = t * t;
+            acc[j] = acc[j] + t;
+        }
+    }
+#pragma unroll
+    for (int j = 4; j < 8; ++j) {
+        float t = d[92 + j] - q[92 + j];
+        t = t * t;
+        acc[j] = acc[j] + t;
+    }
+    // accumulators 0..3 add +0.0f in the reference's masked step: x + 0.0f == x for x >= +0
+    const float s0 = acc[0] + acc[4];
+    const float s1 = acc[1] + acc[5];
+    const float s2 = acc[2] + acc[6];
+    const float s3 = acc[3] + acc[7];
+    const float a = s0 + s1;
+    const float b2 = s2 + s3;
+    return a + b2;
+}
+
+// Packed form of the same arithmetic for gfx950's v_pk_add_f32 / v_pk_mul_f32 (two f32 lanes per
+// VGPR pair, each lane an independent IEEE operation, so the bits are those of the scalar form).
+// acc2[k] holds accumulators (2k, 2k+1); dims (8b+2k, 8b+2k+1) feed acc2[k]; the masked tail puts
+// dims 96..99 into accumulators 4..7 = acc2[2], acc2[3]; the hsum tree
+// ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) starts with two packed adds.
+// `d2` / `q2` are indexable sequences of 50 float pairs (dims 2i, 2i+1).
+typedef float hvs_f2 __attribute__((ext_vector_type(2)));
+
+template <typename DV2, typename QV2>
+__device__ __forceinline__ float hvs_exact_dist_pk(const DV2& d2, const QV2& q2)
+{
+    hvs_f2 acc2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc2[k] = hvs_f2{0.0f, 0.0f};
+#pragma unroll
+    for (int b = 0; b < 12; ++b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hvs_f2 t = d2[4 * b + k] - q2[4 * b + k];
+            t = t * t;
+            acc2[k] = acc2[k] + t;
+        }
+    }
+#pragma unroll
+    for (int k = 2; k < 4; ++k) {
+        hvs_f2 t = d2[46 + k] - q2[46 + k];
+        t = t * t;
+        acc2[k] = acc2[k] + t;
+    }
+    const hvs_f2 s01 = acc2[0] + acc2[2];  // (a0+a4, a1+a5)
+    const hvs_f2 s23 = acc2[1] + acc2[3];  // (a2+a6, a3+a7)
+    const float a = s01.x + s01.y;
+    const float b2 = s23.x + s23.y;
+    return a + b2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate keys: (distance bits << 32) | row id.  Distances are sums of squares (>= +0), so
+// their IEEE bit patterns order like unsigned integers and ascending u64 order is exactly the
+// canonical result order (dist asc, id asc) of SURVEY.md 8c.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t hvs_make_key(float dist, uint32_t id)
+{
+    return ((uint64_t)__float_as_uint(dist) << 32) | (uint64_t)id;
+}
+__device__ __forceinline__ float hvs_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
+__device__ __forceinline__ uint32_t hvs_key_id(uint64_t key) { return (uint32_t)key; }
+
+__device__ __forceinline__ uint32_t hvs_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t hvs_prefix_count(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave_select_prune: the wave-level counterpart of the reference's Knn container bookkeeping
+// (include/optimized_impl.h:284-311 check_add/find_worst, :337-385 merge): instead of evicting
+// the worst slot on every insertion, candidates are appended to a list and the list is cut back
+// to its KEEP smallest keys when it fills up.  MSB-first radix select over the 64-bit keys
+// (ballot + popcount per bit), then an in-place ordered compaction.  Keys must be distinct.
+// All 64 lanes must call it (wave-uniform control flow).  `list` holds `cnt` <= 256 keys in
+// memory visible to the whole wave.  Returns the KEEP-th smallest key; the list then holds
+// exactly KEEP keys.  Precondition: cnt > KEEP.
+// ---------------------------------------------------------------------------------------------
+template <int KEEP>
+__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t lane)
+{
+    uint64_t k[4];
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t idx = lane + 64u * i;
+        valid[i] = idx < cnt;
+        k[i] = valid[i] ? list[idx] : ~0ull;
+    }
+    uint64_t prefix = 0;
+    uint32_t r = KEEP;
+    for (int bit = 63; bit >= 0; --bit) {
+        const uint64_t himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
+        uint32_t c0 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool m = valid[i] && (((k[i] ^ prefix) & himask) == 0ull) && (((k[i] >> bit) & 1ull) == 0ull);
+            c0 += (uint32_t)__popcll(__ballot(m));
+        }
+        if (r > c0) {
+            r -= c0;
+            prefix |= (1ull << bit);
+        }
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool keep = valid[i] && k[i] <= prefix;
+        const uint64_t mask = __ballot(keep);
+        if (keep) list[base + hvs_prefix_count(mask)] = k[i];
+        base += (uint32_t)__popcll(mask);
+    }
+    return prefix;
+}

@@ -1,0 +1,223 @@
+// hvs_kernels.h -- gfx950 kernels of the exact engine (FP32 exact-order scan + top-100 select).
+#pragma once
+
+#include "hvs_device.h"
+#include "../../include/hvs_gen.h"
+
+#define HVS_CAND_CAP 256  // per (query, row-chunk) candidate list capacity (keys)
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic inputs generated in HBM (include/hvs_gen.h), one thread per element.
+// ---------------------------------------------------------------------------------------------
+__global__ void hvs_k_gen_data(float* __restrict__ out, uint64_t nelem, uint64_t seed, int profile, uint32_t ncat)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += stride) {
+        const uint64_t row = e / HVS_DCOLS;
+        const uint32_t col = (uint32_t)(e - row * HVS_DCOLS);
+        out[e] = hvs_gen_data_elem(seed, profile, ncat, row, col);
+    }
+}
+
+__global__ void hvs_k_gen_queries(float* __restrict__ out, uint64_t nelem, uint64_t seed, int profile, uint32_t ncat,
+                                  int force_type, uint64_t first_row)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += stride) {
+        const uint64_t row = e / HVS_QCOLS;
+        const uint32_t col = (uint32_t)(e - row * HVS_QCOLS);
+        out[e] = hvs_gen_query_elem(seed, profile, ncat, force_type, first_row + row, col);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query scheduling keys.  Queries are independent (optimized_parallel.hpp:91 carries no state
+// between iterations), so the engine may answer them in any order: they are grouped by
+// (type, v, l) so that the 64 queries of a wavefront share one predicate shape and a row that
+// no lane wants is skipped by the whole wave.
+// key = type:3 | float(v) as ordered u32:32 | top 29 bits of ordered(l)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hvs_ordered_u32(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void hvs_k_query_keys(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint64_t* __restrict__ keys,
+                                 uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
+    const uint32_t vk = (p.type == 1u || p.type == 3u) ? hvs_ordered_u32(p.vf) : 0u;
+    const uint32_t lk = (p.type == 2u || p.type == 3u) ? hvs_ordered_u32(p.l) : 0u;
+    keys[i] = ((uint64_t)p.type << 61) | ((uint64_t)vk << 29) | (uint64_t)(lk >> 3);
+    idx[i] = q0 + i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_scan_exact -- the reference's inner hot loop (optimized_parallel.hpp:100-139 +
+// optimized_impl.h:54-125,284-311) re-shaped for a 64-wide wavefront:
+//
+//   * one LANE per QUERY: the query's 100 dims live in 100 VGPRs for the whole kernel, the
+//     running threshold tau and the list fill are per-lane registers;
+//   * the DATA ROW is wave-uniform: it is fetched through the scalar cache into SGPRs and fed
+//     to v_sub_f32 as the scalar operand, so one 408-byte row fetch serves 64 (query,row) pairs
+//     and costs no VGPRs, no LDS and no vector-memory instruction;
+//   * predicates (C == v, l <= T <= r) are evaluated per lane on the scalar C,T; a row no lane
+//     accepts is skipped by the whole wave (one ballot + scalar branch);
+//   * the distance is the reference's exact order (8 accumulators, no FMA), 300 VALU ops/pair;
+//   * admission is the reference's strict `dist < worst` (optimized_impl.h:301): accepted pairs
+//     are appended to the lane's private list in global memory; a full list is cut back to its
+//     100 smallest (dist,id) keys by the whole wave (hvs_wave_select_prune), which also gives
+//     the new tau.  Rows are scanned in ascending id, so a later row with dist == tau can never
+//     displace a kept one under the canonical (dist asc, id asc) order.
+//
+// Grid: x = blocks of 4 query-waves (256 queries), y = row chunk.  Waves never synchronise
+// with each other.  Output: per (chunk, query slot) a list of <= HVS_CAND_CAP keys + its fill.
+// ---------------------------------------------------------------------------------------------
+struct HvsUniformRow2 {
+    const hvs_f2* __restrict__ p;  // row + 2 floats: 8-byte aligned (row stride 408 B)
+    __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
+};
+
+__global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
+    const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
+    uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+    unsigned long long* __restrict__ counters)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t qwave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = qwave * 64u + lane;
+    const uint32_t chunk = blockIdx.y;
+    if (qwave * 64u >= nq) return;  // wave-uniform
+
+    const bool have_q = slot < nq;
+    const uint32_t qi = qorder[have_q ? slot : nq - 1u];
+    const float* __restrict__ qrow = Q + (size_t)qi * HVS_QCOLS;
+    HvsQParams p = hvs_parse_query(qrow);
+    if (!have_q) p.type = 4u;
+
+    hvs_f2 q2[HVS_NDIM / 2];
+#pragma unroll
+    for (int i = 0; i < HVS_NDIM / 4; ++i) {
+        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 4 * i);
+        q2[2 * i] = hvs_f2{v4.x, v4.y};
+        q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
+    }
+
+    const uint32_t r0 = chunk * rows_per_chunk;
+    uint32_t r1 = r0 + rows_per_chunk;
+    if (r1 > sn || r1 < r0) r1 = sn;
+
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
+    float tau = __builtin_inff();
+    uint32_t cnt = 0;
+    uint32_t npass = 0, nscan = 0;  // per-wave statistics (uniform)
+
+    for (uint32_t j = r0; j < r1; ++j) {
+        const float* __restrict__ row = D + (size_t)j * HVS_DCOLS;
+        const float C = row[0];
+        const float T = row[1];
+        const bool pass = hvs_row_passes(p, C, T);
+        const uint64_t pmask = __ballot(pass);
+        if (pmask == 0ull) continue;
+        npass += (uint32_t)__popcll(pmask);
+        nscan += 64u;
+
+        HvsUniformRow2 dv{reinterpret_cast<const hvs_f2*>(row + 2)};
+        const float dist = hvs_exact_dist_pk(dv, q2);
+
+        if (pass && dist < tau) {
+            mylist[cnt] = hvs_make_key(dist, j);
+            ++cnt;
+        }
+        uint64_t full = __ballot(cnt == HVS_CAND_CAP);
+        if (full != 0ull) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            while (full != 0ull) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(full);
+                full &= full - 1ull;
+                uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * HVS_CAND_CAP;
+                const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, HVS_CAND_CAP, lane);
+                if (lane == l) {
+                    cnt = HVS_KNN;
+                    tau = hvs_key_dist(kth);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    if (have_q) cand_cnt[(size_t)chunk * nq_pad + slot] = cnt;
+    if (lane == 0u) {
+        atomicAdd(&counters[0], (unsigned long long)npass);
+        atomicAdd(&counters[1], (unsigned long long)nscan);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_select -- per query: merge the per-chunk candidate lists (the counterpart of
+// Knn::merge, optimized_impl.h:337-385 + optimized_parallel.hpp:142-146), pad with the last
+// rows of D when fewer than 100 rows matched (optimized_parallel.hpp:149-157: rows n-1, n-2,
+// ... regardless of predicate or duplicates, distances by the same exact-order kernel) and
+// emit ids in ascending (dist, id) order (get_knn_sorted, optimized_impl.h:392-415).
+// One wave per query, 4 queries per 256-thread block, a 256-key LDS buffer per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvs_k_select(
+    const float* __restrict__ D, uint32_t n, const float* __restrict__ Q, const uint32_t* __restrict__ qorder,
+    uint32_t nq, uint32_t nq_pad, uint32_t nchunks, const uint64_t* __restrict__ cand,
+    const uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+{
+    __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * 4u + w;
+    if (slot >= nq) return;  // wave-uniform
+    uint64_t* buf = sbuf[w];
+    const uint32_t qi = qorder[slot];
+
+    uint32_t cnt = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t m = cand_cnt[(size_t)c * nq_pad + slot];
+        const uint64_t* __restrict__ lst = cand + ((size_t)c * nq_pad + slot) * HVS_CAND_CAP;
+        for (uint32_t off = 0; off < m; off += 64u) {
+            if (cnt + 64u > HVS_CAND_CAP) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+                cnt = HVS_KNN;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            const uint32_t take = (m - off) < 64u ? (m - off) : 64u;
+            if (lane < take) buf[cnt + lane] = lst[off + lane];
+            cnt += take;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (cnt > HVS_KNN) {
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        cnt = HVS_KNN;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    // padding: fewer than 100 matching rows in [0,sn)
+    const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
+    for (uint32_t base = cnt; base < HVS_KNN; base += 64u) {
+        const uint32_t e = base + lane;
+        if (e < HVS_KNN) {
+            const uint32_t id = n - 1u - (e - cnt);
+            const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
+            buf[e] = hvs_make_key(hvs_exact_dist(dv, qv), id);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // rank sort of exactly 100 keys (duplicates possible after padding: ties broken by slot)
+    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+        const uint64_t ke = buf[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+            const uint64_t kj = buf[j];
+            rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
+        }
+        out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = hvs_key_dist(ke);
+    }
+}

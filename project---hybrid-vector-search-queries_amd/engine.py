@@ -1,0 +1,203 @@
+"""ctypes binding of libhvs.so (C ABI: include/hvs.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_CSRC, "libhvs.so")
+_HDR = os.path.join(_REPO, "include", "hvs.h")
+
+ENGINE_AUTO, ENGINE_EXACT_SCAN, ENGINE_MFMA_FILTER = 0, 1, 2
+K, DCOLS, QCOLS = 100, 102, 104
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+class HvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hvs error {code}: {msg}")
+        self.code = code
+
+
+class Timing(C.Structure):
+    _fields_ = [("query_ms", C.c_double), ("main_kernel_ms", C.c_double), ("main_kernel_launches", C.c_uint32),
+                ("nq", C.c_uint32), ("pairs", C.c_uint64), ("scanned_pairs", C.c_uint64), ("load_ms", C.c_double),
+                ("engine", C.c_uint32), ("fallback_queries", C.c_uint32)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def library_path():
+    return _LIB
+
+
+def sources():
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h"))] + [
+        _HDR, os.path.join(_REPO, "include", "hvs_gen.h")]
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/hvs.hip for gfx950 into csrc/libhvs.so (hipcc cross-compiles without a GPU)."""
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in sources()):
+        return _LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "hvs.hip"), "-o", _LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_CSRC)
+    return _LIB
+
+
+def exported_symbols():
+    """Names declared in include/hvs.h (every one must be exported by libhvs.so)."""
+    txt = open(_HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hvs_[a-z_0-9]+)\s*\(", txt)))
+
+
+_lib = None
+_f32p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+
+
+def library():
+    """Load libhvs.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise HvsError(-100, f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(_LIB)
+    vp = C.c_void_p
+    sig = {
+        "hvs_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "hvs_destroy": (None, [vp]),
+        "hvs_last_error": (C.c_char_p, [vp]),
+        "hvs_last_global_error": (C.c_char_p, []),
+        "hvs_set_engine": (C.c_int, [vp, C.c_int]),
+        "hvs_load_data": (C.c_int, [vp, _f32p, C.c_uint32]),
+        "hvs_gen_data": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32]),
+        "hvs_download_data": (C.c_int, [vp, C.c_uint32, C.c_uint32, _f32p]),
+        "hvs_num_rows": (C.c_uint32, [vp]),
+        "hvs_query": (C.c_int, [vp, _f32p, C.c_uint32, C.c_float, _u32p, _f32p]),
+        "hvs_upload_queries": (C.c_int, [vp, _f32p, C.c_uint32]),
+        "hvs_gen_queries": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_uint64]),
+        "hvs_download_queries": (C.c_int, [vp, C.c_uint32, C.c_uint32, _f32p]),
+        "hvs_query_resident": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float]),
+        "hvs_sync": (C.c_int, [vp]),
+        "hvs_download_results": (C.c_int, [vp, C.c_uint32, C.c_uint32, _u32p, _f32p]),
+        "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
+        "hvs_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _up(a):
+    return a.ctypes.data_as(_u32p)
+
+
+class Engine:
+    """One hvs_ctx: one GPU, one stream, D resident in HBM."""
+
+    def __init__(self, device=-1):
+        self._lib = library()
+        h = C.c_void_p()
+        rc = self._lib.hvs_create(C.byref(h), device)
+        if rc != 0:
+            raise HvsError(rc, self._lib.hvs_last_global_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hvs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HvsError(rc, self._lib.hvs_last_error(self._h).decode())
+
+    def set_engine(self, engine):
+        self._ck(self._lib.hvs_set_engine(self._h, engine))
+
+    # --- data
+    def load_data(self, rows):
+        rows = np.ascontiguousarray(rows, np.float32)
+        if rows.ndim != 2 or rows.shape[1] != DCOLS:
+            raise HvsError(-1, "data rows must be n x 102 float32")
+        self._ck(self._lib.hvs_load_data(self._h, _fp(rows), rows.shape[0]))
+
+    def gen_data(self, n, seed, profile=1, ncat=100):
+        self._ck(self._lib.hvs_gen_data(self._h, n, seed, profile, ncat))
+
+    def download_data(self, row0, nrows):
+        out = np.empty((nrows, DCOLS), np.float32)
+        self._ck(self._lib.hvs_download_data(self._h, row0, nrows, _fp(out)))
+        return out
+
+    @property
+    def n(self):
+        return int(self._lib.hvs_num_rows(self._h))
+
+    # --- the vec_query seam
+    def query(self, q_rows, sample_proportion=1.0, want_dists=True):
+        q = np.ascontiguousarray(q_rows, np.float32)
+        if q.ndim != 2 or q.shape[1] != QCOLS:
+            raise HvsError(-1, "query rows must be nq x 104 float32")
+        nq = q.shape[0]
+        ids = np.empty((nq, K), np.uint32)
+        d = np.empty((nq, K), np.float32) if want_dists else None
+        self._ck(self._lib.hvs_query(self._h, _fp(q), nq, sample_proportion, _up(ids), _fp(d) if want_dists else None))
+        return (ids, d) if want_dists else ids
+
+    # --- resident variant
+    def upload_queries(self, q_rows):
+        q = np.ascontiguousarray(q_rows, np.float32)
+        self._ck(self._lib.hvs_upload_queries(self._h, _fp(q), q.shape[0]))
+
+    def gen_queries(self, nq, seed, profile=1, ncat=100, force_type=-1, first_row=0):
+        self._ck(self._lib.hvs_gen_queries(self._h, nq, seed, profile, ncat, force_type, first_row))
+
+    def download_queries(self, q0, nq):
+        out = np.empty((nq, QCOLS), np.float32)
+        self._ck(self._lib.hvs_download_queries(self._h, q0, nq, _fp(out)))
+        return out
+
+    def query_resident(self, q0, nq, sample_proportion=1.0):
+        self._ck(self._lib.hvs_query_resident(self._h, q0, nq, sample_proportion))
+
+    def sync(self):
+        self._ck(self._lib.hvs_sync(self._h))
+
+    def download_results(self, q0, nq, want_dists=True):
+        ids = np.empty((nq, K), np.uint32)
+        d = np.empty((nq, K), np.float32) if want_dists else None
+        self._ck(self._lib.hvs_download_results(self._h, q0, nq, _up(ids), _fp(d) if want_dists else None))
+        return (ids, d) if want_dists else ids
+
+    def last_timing(self):
+        t = Timing()
+        self._ck(self._lib.hvs_last_timing(self._h, C.byref(t)))
+        return t
