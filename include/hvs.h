@@ -98,6 +98,9 @@ int hvs_download_queries(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float *out_rows
 int hvs_query_resident(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float sample_proportion);
 int hvs_sync(hvs_ctx *ctx);
 int hvs_download_results(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *out_ids, float *out_dists);
+/* Copy result rows [q0,q0+nq) into caller-owned DEVICE buffers (same GPU), e.g. a collective's
+ * send buffer.  d_dists may be NULL.  Asynchronous on the context stream. */
+int hvs_export_results_device(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *d_ids, float *d_dists);
 /* Timing of the last hvs_query / hvs_query_resident (call after hvs_sync). */
 int hvs_last_timing(hvs_ctx *ctx, hvs_timing *out);
 

@@ -450,6 +450,19 @@ int hvs_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_ids
     return HVS_OK;
 }
 
+int hvs_export_results_device(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* d_ids, float* d_dists)
+{
+    if (!c) return HVS_EINVAL;
+    if (!d_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_export_results_device: bad range");
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipMemcpyAsync(d_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, c->stream));
+    if (d_dists)
+        HVS_HIP(c, hipMemcpyAsync(d_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
+                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return HVS_OK;
+}
+
 int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids,
               float* out_dists)
 {

@@ -93,6 +93,7 @@ def library():
         "hvs_query_resident": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float]),
         "hvs_sync": (C.c_int, [vp]),
         "hvs_download_results": (C.c_int, [vp, C.c_uint32, C.c_uint32, _u32p, _f32p]),
+        "hvs_export_results_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
         "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
         "hvs_version": (C.c_char_p, []),
     }
@@ -196,6 +197,11 @@ class Engine:
         d = np.empty((nq, K), np.float32) if want_dists else None
         self._ck(self._lib.hvs_download_results(self._h, q0, nq, _up(ids), _fp(d) if want_dists else None))
         return (ids, d) if want_dists else ids
+
+    def export_results_device(self, q0, nq, ids_ptr, dists_ptr=None):
+        """Copy results into device buffers given as raw pointers (e.g. torch tensor.data_ptr())."""
+        self._ck(self._lib.hvs_export_results_device(self._h, q0, nq, C.c_void_p(ids_ptr),
+                                                     C.c_void_p(dists_ptr) if dists_ptr else None))
 
     def last_timing(self):
         t = Timing()
