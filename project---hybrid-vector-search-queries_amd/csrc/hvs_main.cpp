@@ -1,0 +1,117 @@
+// hvs_main.cpp -- command-line driver with the reference's process-level contract
+// (reference src/test.cpp:20-111):
+//     hvs_search.out [source_path] [query_path] [output_path]
+// defaults ../data/default-data.bin, ../data/query.bin, ../result_data/hvs.bin; any other argc
+// prints the usage line and exits 1 (test.cpp:51-64).  Reads D / Q in the io.h format
+// (io.h:111-136) with one bulk read each, times only the vec_query-equivalent region
+// (test.cpp:82-88: data already in host memory -> ids back in host memory), prints
+// "Vector Search took <ms> ms" on stderr (test.cpp:91-92), writes output.bin (io.h:23-36) and
+// <output>.dist with the scalar-order distances of the chosen rows (test.cpp:97-110, io.h:38-78).
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/hvs.h"
+
+static bool read_bin(const std::string& path, uint32_t cols, std::vector<float>& rows, uint32_t& n)
+{
+    std::cout << "Reading Data: " << path << std::endl;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint32_t hdr = 0;
+    if (std::fread(&hdr, sizeof(hdr), 1, f) != 1) {
+        std::fclose(f);
+        return false;
+    }
+    std::cout << "# of points: " << hdr << std::endl;
+    rows.resize((size_t)hdr * cols);
+    const size_t got = std::fread(rows.data(), sizeof(float) * cols, hdr, f);
+    std::fclose(f);
+    n = (uint32_t)got;  // like io.h:125 only whole rows actually present are used
+    rows.resize((size_t)n * cols);
+    std::cout << "Finish Reading Data" << std::endl;
+    return true;
+}
+
+int main(int argc, char** argv)
+{
+    std::cout << "Running MI355X Vector Search\n";
+    std::string source_path = "../data/default-data.bin";
+    std::string query_path = "../data/query.bin";
+    std::string knn_save_path = "../result_data/hvs.bin";
+    switch (argc) {
+    case 4: knn_save_path = argv[3]; [[fallthrough]];
+    case 3: query_path = argv[2]; [[fallthrough]];
+    case 2: source_path = argv[1]; [[fallthrough]];
+    case 1: break;
+    default: std::cout << argv[0] << " [source_path] [query_path] [output_path]\n"; return 1;
+    }
+    const float sample_proportion = 1.0f;  // test.cpp:68
+
+    std::vector<float> nodes, queries;
+    uint32_t n = 0, nq = 0;
+    if (!read_bin(source_path, 102, nodes, n)) {
+        std::cerr << "cannot read " << source_path << "\n";
+        return 2;
+    }
+    std::cout << n << "\n";
+    if (!read_bin(query_path, 104, queries, nq)) {
+        std::cerr << "cannot read " << query_path << "\n";
+        return 2;
+    }
+
+    hvs_ctx* ctx = nullptr;
+    if (hvs_create(&ctx, -1) != HVS_OK) {
+        std::cerr << hvs_last_global_error() << "\n";
+        return 3;
+    }
+    std::vector<uint32_t> ids((size_t)nq * 100);
+    std::cout << "# data points:  " << n << "\n# data point dim:  102\n# queries:      " << nq << "\n";
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = hvs_load_data(ctx, nodes.data(), n);
+    if (rc == HVS_OK && nq) rc = hvs_query(ctx, queries.data(), nq, sample_proportion, ids.data(), nullptr);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != HVS_OK) {
+        std::cerr << "hvs error " << rc << ": " << hvs_last_error(ctx) << "\n";
+        hvs_destroy(ctx);
+        return 3;
+    }
+    hvs_timing tm{};
+    if (nq) hvs_last_timing(ctx, &tm);
+    std::cerr << "Vector Search took " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms"
+              << " (device query " << tm.query_ms << " ms, data upload+index " << tm.load_ms << " ms)" << std::endl;
+    hvs_destroy(ctx);
+
+    FILE* f = std::fopen(knn_save_path.c_str(), "wb");
+    if (!f) {
+        std::cerr << "cannot write " << knn_save_path << "\n";
+        return 2;
+    }
+    std::fwrite(ids.data(), sizeof(uint32_t), ids.size(), f);
+    std::fclose(f);
+
+    f = std::fopen((knn_save_path + ".dist").c_str(), "wb");
+    if (!f) return 2;
+    std::fwrite(&nq, sizeof(uint32_t), 1, f);
+    std::vector<float> line(100);
+    for (uint32_t i = 0; i < nq; ++i) {
+        for (int k = 0; k < 100; ++k) {
+            const float* a = &nodes[(size_t)ids[(size_t)i * 100 + k] * 102];
+            const float* b = &queries[(size_t)i * 104 + 4];
+            float sum = 0.0f;  // io.h:38-48 calc_dist: sequential order
+            for (int x = 0; x < 100; ++x) {
+                float diff = a[2 + x] - b[x];
+                diff = diff * diff;
+                sum = sum + diff;
+            }
+            line[k] = sum;
+        }
+        std::fwrite(line.data(), sizeof(float), 100, f);
+    }
+    std::fclose(f);
+    return 0;
+}

@@ -40,7 +40,7 @@ def library_path():
 
 
 def sources():
-    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h"))] + [
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h", ".cpp"))] + [
         _HDR, os.path.join(_REPO, "include", "hvs_gen.h")]
 
 
@@ -53,7 +53,22 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=_CSRC)
+    build_cli(verbose)
     return _LIB
+
+
+def cli_path():
+    return os.path.join(_CSRC, "hvs_search.out")
+
+
+def build_cli(verbose=False):
+    """The reference-compatible command-line driver (csrc/hvs_main.cpp, argv contract of src/test.cpp)."""
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", os.path.join(_CSRC, "hvs_main.cpp"), "-L" + _CSRC, "-lhvs",
+           "-Wl,-rpath,$ORIGIN", "-o", cli_path()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_CSRC)
+    return cli_path()
 
 
 def exported_symbols():

@@ -138,3 +138,22 @@ def test_vec_query_mirror(eng):
     assert res[0] == [1, 2, 3] and len(res) == 41     # appends, does not clear (optimized_parallel.hpp:159)
     ref, _ = T.oracle_query(nodes, queries)
     T.check_parity(nodes, queries, np.array(res[1:], np.uint32), ref)
+
+
+def test_cli_driver_matches_reference_files(tmp_path):
+    """csrc/hvs_search.out keeps the reference's argv contract and file formats (src/test.cpp:51-110)."""
+    import subprocess
+    z = np.load(os.path.join(T.GOLDEN_DIR, "config1_10k_x100.npz"))
+    nodes, queries = _inputs(z)
+    d, q, o = str(tmp_path / "d.bin"), str(tmp_path / "q.bin"), str(tmp_path / "out.bin")
+    T.write_bin(d, nodes)
+    T.write_bin(q, queries)
+    r = subprocess.run([PKG.cli_path(), d, q, o], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Vector Search took" in r.stderr
+    ids = T.read_knn(o)
+    T.check_parity(nodes, queries, ids, z["ids_optimized"])
+    want = T.oracle_dists_for_ids(nodes, queries, ids, order="scalar")
+    assert np.array_equal(T.read_dist_file(o + ".dist").view(np.uint32), want.view(np.uint32))
+    bad = subprocess.run([PKG.cli_path(), "a", "b", "c", "d"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "[source_path] [query_path] [output_path]" in bad.stdout
