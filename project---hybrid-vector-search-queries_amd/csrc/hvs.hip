@@ -15,6 +15,7 @@
 
 #include "../../include/hvs.h"
 #include "hvs_kernels.h"
+#include "hvs_filter.h"
 
 namespace {
 
@@ -55,6 +56,22 @@ struct hvs_ctx {
     size_t cand_lists = 0;
     unsigned long long* d_counters = nullptr;
 
+    // ---- MFMA engine: index over D (two orderings) ...
+    bool have_index = false;
+    HvsLevels lv{};                       // same block count for both orderings
+    uint64_t *d_keys_ct = nullptr, *d_keys_t = nullptr;   // sorted attribute keys
+    uint32_t *d_perm_ct = nullptr, *d_perm_t = nullptr;   // position -> original row id
+    uint4 *d_tiles_ct = nullptr, *d_tiles_t = nullptr;    // BF16 A-operand tiles, level-interleaved
+    uint32_t *d_bpos_ct = nullptr, *d_bpos_t = nullptr;   // storage index -> block
+    HvsBounds* d_bounds = nullptr;
+    double index_ms = 0.0;
+    // ... and per-batch state
+    HvsBatch fb{};
+    uint32_t fb_slots_cap = 0;
+    uint32_t* d_layout = nullptr;
+    uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
+    uint32_t fallback_queries = 0;
+
     hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;
     static constexpr int kMaxLaunchEvents = 64;
     hipEvent_t ev_k0[kMaxLaunchEvents], ev_k1[kMaxLaunchEvents];
@@ -65,7 +82,9 @@ struct hvs_ctx {
 
 namespace {
 
-constexpr uint32_t kBatch = 65536;  // queries answered per pass over D
+constexpr uint32_t kBatch = 65536;        // queries answered per pass over D (exact engine)
+constexpr uint32_t kBatchMfma = 131072;   // queries per batch of the MFMA engine
+constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 
 int fail(hvs_ctx* c, int code, const std::string& msg)
 {
@@ -169,34 +188,252 @@ int ensure_batch_workspace(hvs_ctx* c, uint32_t nqb, const Plan& p)
     return HVS_OK;
 }
 
-// One batch [q0, q0+nqb) of resident queries through the exact engine.
-int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
+// One batch of resident queries through the exact engine.  Either the contiguous range
+// [q0, q0+nqb) (sorted into predicate groups first) or, when `list` is given, the nqb query
+// indices stored in the device array `list` (the MFMA engine's overflow fallback).
+int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list = nullptr,
+                    bool count_stats = true)
 {
     const Plan p = make_plan(nqb, sn);
     int rc = ensure_batch_workspace(c, nqb, p);
     if (rc) return rc;
 
-    hipLaunchKernelGGL(hvs_k_query_keys, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
-                       c->d_keys, c->d_qidx);
-    size_t tmp = c->sort_tmp_bytes;
-    HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
-                                         (size_t)nqb, 0, 64, c->stream));
+    const uint32_t* qorder = list;
+    if (!list) {
+        hipLaunchKernelGGL(hvs_k_query_keys, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
+                           c->d_keys, c->d_qidx);
+        size_t tmp = c->sort_tmp_bytes;
+        HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
+                                             (size_t)nqb, 0, 64, c->stream));
+        qorder = c->d_qorder;
+    }
     HVS_HIP(c, hipMemsetAsync(c->d_cand_cnt, 0, (size_t)p.nq_pad * p.nchunks * sizeof(uint32_t), c->stream));
 
-    const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
+    const int ev = (count_stats && c->n_launch_events < hvs_ctx::kMaxLaunchEvents) ? c->n_launch_events : -1;
     if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
     if (sn > 0) {
         hipLaunchKernelGGL(hvs_k_scan_exact, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream, c->d_data,
-                           c->d_q, c->d_qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
-                           c->d_counters);
+                           c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
+                           count_stats ? c->d_counters : c->d_counters + 4);
     }
     if (ev >= 0) {
         HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
         c->n_launch_events++;
     }
     hipLaunchKernelGGL(hvs_k_select, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                       c->d_qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+                       qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
     HVS_HIP(c, hipGetLastError());
+    return HVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA engine: index build
+// ---------------------------------------------------------------------------------------------
+HvsLevels make_levels(uint32_t n)
+{
+    HvsLevels L{};
+    L.nblk = (n + 31u) / 32u;
+    uint32_t K = 0;
+    while (K < 14u && (L.nblk >> (2u * (K + 1u))) >= 64u) ++K;  // level 0 keeps >= 64 blocks (2048 rows)
+    L.K = K;
+    uint32_t off = 0;
+    for (uint32_t j = 0; j <= K; ++j) {
+        L.off[j] = off;
+        const uint32_t s = 1u << (2u * (K - j));
+        const uint32_t t = hvs_ceil_div(L.nblk, s);
+        off += (j == 0) ? t : hvs_g4(t);
+    }
+    for (uint32_t j = K + 1; j < 16u; ++j) L.off[j] = off;
+    return L;
+}
+
+void free_index(hvs_ctx* c)
+{
+    void* ptrs[] = {c->d_keys_ct, c->d_keys_t, c->d_perm_ct, c->d_perm_t, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_keys_ct = c->d_keys_t = nullptr;
+    c->d_perm_ct = c->d_perm_t = nullptr;
+    c->d_tiles_ct = c->d_tiles_t = nullptr;
+    c->d_bpos_ct = c->d_bpos_t = nullptr;
+    c->have_index = false;
+}
+
+int build_index(hvs_ctx* c)
+{
+    free_index(c);
+    const uint32_t n = c->n;
+    const HvsLevels L = make_levels(n);
+    if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
+    c->lv = L;
+    int rc;
+    uint64_t *k_ct = nullptr, *k_t = nullptr;
+    uint32_t* ids = nullptr;
+    void* tmp = nullptr;
+    auto cleanup = [&]() {
+        if (k_ct) (void)hipFree(k_ct);
+        if (k_t) (void)hipFree(k_t);
+        if (ids) (void)hipFree(ids);
+        if (tmp) (void)hipFree(tmp);
+    };
+#define HVS_TRY(expr)            \
+    do {                         \
+        if ((rc = (expr))) {     \
+            cleanup();           \
+            free_index(c);       \
+            return rc;           \
+        }                        \
+    } while (0)
+    HVS_TRY(dev_alloc(c, &k_ct, (size_t)n));
+    HVS_TRY(dev_alloc(c, &k_t, (size_t)n));
+    HVS_TRY(dev_alloc(c, &ids, (size_t)n));
+    HVS_TRY(dev_alloc(c, &c->d_keys_ct, (size_t)n));
+    HVS_TRY(dev_alloc(c, &c->d_keys_t, (size_t)n));
+    HVS_TRY(dev_alloc(c, &c->d_perm_ct, (size_t)n));
+    HVS_TRY(dev_alloc(c, &c->d_perm_t, (size_t)n));
+    hipLaunchKernelGGL(hvs_k_attr_keys, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, k_ct, k_t, ids);
+    size_t tmp_bytes = 0, tmp_bytes_t = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_ct, c->d_keys_ct, ids, c->d_perm_ct, (size_t)n, 0, 64,
+                                             c->stream);
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes_t, k_t, c->d_keys_t, ids, c->d_perm_t, (size_t)n, 0, 64, c->stream);
+    if (tmp_bytes_t > tmp_bytes) tmp_bytes = tmp_bytes_t;  // each call sizes its own algorithm
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_ct, c->d_keys_ct, ids, c->d_perm_ct, (size_t)n, 0, 64, c->stream);
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_t, c->d_keys_t, ids, c->d_perm_t, (size_t)n, 0, 64, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        free_index(c);
+        return fail(c, e == hipErrorOutOfMemory ? HVS_ENOMEM : HVS_EHIP, std::string("index sort: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    k_ct = k_t = nullptr;
+    ids = nullptr;
+    tmp = nullptr;
+    HVS_TRY(dev_alloc(c, &c->d_tiles_ct, (size_t)L.nblk * HVS_TILE_U4));
+    HVS_TRY(dev_alloc(c, &c->d_tiles_t, (size_t)L.nblk * HVS_TILE_U4));
+    HVS_TRY(dev_alloc(c, &c->d_bpos_ct, (size_t)L.nblk));
+    HVS_TRY(dev_alloc(c, &c->d_bpos_t, (size_t)L.nblk));
+#undef HVS_TRY
+    if (!c->d_bounds) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_bounds), sizeof(HvsBounds)));
+    HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
+    const dim3 grid((L.nblk + 3u) / 4u);
+    hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_tiles_ct,
+                       c->d_bpos_ct, c->d_bounds);
+    hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_tiles_t,
+                       c->d_bpos_t, c->d_bounds);
+    HVS_HIP(c, hipGetLastError());
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_index = true;
+    return HVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA engine: one batch
+// ---------------------------------------------------------------------------------------------
+int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
+{
+    const uint32_t slots = hvs_ceil_div(nqb + 5u * 32u + 2u * HVS_GROUP, HVS_GROUP) * HVS_GROUP;
+    HvsBatch& B = c->fb;
+    if (slots > c->fb_slots_cap) {
+        int rc;
+        const uint32_t groups = slots / HVS_GROUP;
+#define HVS_A(field, count) \
+    if ((rc = dev_alloc(c, &B.field, (size_t)(count)))) return rc
+        HVS_A(qid, slots);
+        HVS_A(rank, slots);
+        HVS_A(ra, slots);
+        HVS_A(rb, slots);
+        HVS_A(gua, groups);
+        HVS_A(gub, groups);
+        HVS_A(gord, groups);
+        HVS_A(bfrag, (size_t)(slots / 32u) * HVS_TILE_U4);
+        HVS_A(theta, slots);
+        HVS_A(qn, slots);
+        HVS_A(normq, slots);
+        HVS_A(eq, slots);
+        HVS_A(nqb, slots);
+        HVS_A(top, (size_t)slots * HVS_TOPCAP);
+        HVS_A(topcnt, slots);
+        HVS_A(tau, slots);
+        HVS_A(cand, (size_t)slots * HVS_FCAP);
+        HVS_A(candcnt, slots);
+        HVS_A(overflow, slots);
+        HVS_A(pairs, (size_t)groups * HVS_GCAP);
+        HVS_A(paircnt, groups);
+        HVS_A(goverflow, groups);
+#undef HVS_A
+        if ((rc = dev_alloc(c, &c->d_ovf_list, (size_t)slots))) return rc;
+        if (!c->d_layout) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_layout), 16 * sizeof(uint32_t)));
+        if (!c->d_ovf_count) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), sizeof(uint32_t)));
+        c->fb_slots_cap = slots;
+    }
+    B.nslots = slots;
+    B.ngroups = slots / HVS_GROUP;
+    // sort workspace shared with the exact engine
+    Plan p{};
+    p.nq_pad = 256;
+    p.nchunks = 1;
+    return ensure_batch_workspace(c, nqb, p);
+}
+
+int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
+{
+    int rc = ensure_filter_workspace(c, nqb);
+    if (rc) return rc;
+    HvsBatch& B = c->fb;
+    const HvsLevels L = c->lv;
+    const uint32_t n = c->n;
+
+    hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys,
+                       c->d_qidx);
+    size_t tmp = c->sort_tmp_bytes;
+    HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
+                                         (size_t)nqb, 0, 64, c->stream));
+    hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, B.qid,
+                       B.rank, c->d_layout);
+    hipLaunchKernelGGL(hvs_k_prep_slots, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, B, c->d_keys_ct,
+                       c->d_keys_t, n, c->d_counters);
+    hipLaunchKernelGGL(hvs_k_prep_groups, dim3(B.ngroups), dim3(HVS_GROUP), 0, c->stream, c->d_q, B);
+    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                       c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
+    hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                       c->d_bounds, L.K == 0u ? 1 : 0, c->d_out_ids, c->d_out_dists);
+    for (uint32_t level = 1; level <= L.K; ++level) {
+        const uint32_t count = L.off[level + 1] - L.off[level];
+        const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
+        HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
+        if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+        hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(count, HVS_SEG) + 1u, hvs_ceil_div(B.ngroups, 4u)), dim3(256),
+                           0, c->stream, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t, L, level, B,
+                           c->d_counters);
+        if (ev >= 0) {
+            HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
+            c->n_launch_events++;
+        }
+        hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, c->d_q, B, c->d_perm_ct,
+                           c->d_perm_t, c->d_counters);
+        hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                           c->d_bounds, level == L.K ? 1 : 0, c->d_out_ids, c->d_out_dists);
+    }
+    // queries whose candidate lists overflowed are answered again by the exact engine
+    HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(hvs_k_collect_overflow, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, B, c->d_ovf_list,
+                       c->d_ovf_count);
+    HVS_HIP(c, hipGetLastError());
+    uint32_t novf = 0;
+    HVS_HIP(c, hipMemcpyAsync(&novf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    if (novf) {
+        c->fallback_queries += novf;
+        for (uint32_t off = 0; off < novf; off += kBatch) {
+            const uint32_t m = std::min(kBatch, novf - off);
+            if ((rc = run_batch_exact(c, 0, m, n, c->d_ovf_list + off, false))) return rc;
+        }
+    }
     return HVS_OK;
 }
 
@@ -206,20 +443,26 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
     HVS_HIP(c, hipSetDevice(c->device));
     const uint32_t sn = sample_rows(sample_proportion, c->n);
+    // the index orders ALL rows; a sampled prefix [0,sn) is answered by the exact engine
+    bool mfma = c->have_index && sn == c->n &&
+                (c->engine == HVS_ENGINE_MFMA_FILTER || (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
     c->timing_valid = false;
     c->n_launch_events = 0;
-    HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    c->fallback_queries = 0;
+    HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
-    for (uint32_t off = 0; off < nq; off += kBatch) {
-        const uint32_t nqb = std::min(kBatch, nq - off);
-        int rc = run_batch_exact(c, q0 + off, nqb, sn);
+    const uint32_t step = mfma ? kBatchMfma : kBatch;
+    for (uint32_t off = 0; off < nq; off += step) {
+        const uint32_t nqb = std::min(step, nq - off);
+        int rc = mfma ? run_batch_mfma(c, q0 + off, nqb) : run_batch_exact(c, q0 + off, nqb, sn);
         if (rc) return rc;
     }
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     c->timing = hvs_timing{};
     c->timing.nq = nq;
-    c->timing.engine = HVS_ENGINE_EXACT_SCAN;
+    c->timing.engine = mfma ? HVS_ENGINE_MFMA_FILTER : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
+    c->timing.fallback_queries = c->fallback_queries;
     c->timing_valid = true;
     return HVS_OK;
 }
@@ -276,7 +519,7 @@ int hvs_create(hvs_ctx** out, int device)
         if ((e = hipEventCreate(&c->ev_k0[i])) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_k1[i])) != hipSuccess) return bail("hipEventCreate", e);
     }
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 4 * sizeof(unsigned long long))) != hipSuccess)
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 8 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
     *out = c;
     return HVS_OK;
@@ -291,6 +534,15 @@ void hvs_destroy(hvs_ctx* c)
                     c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    free_index(c);
+    {
+        HvsBatch& B = c->fb;
+        void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
+                      B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
+                      c->d_bounds, c->d_layout, c->d_ovf_list, c->d_ovf_count};
+        for (void* p : fp)
+            if (p) (void)hipFree(p);
+    }
     if (c->ev_q0) (void)hipEventDestroy(c->ev_q0);
     if (c->ev_q1) (void)hipEventDestroy(c->ev_q1);
     for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
@@ -306,9 +558,13 @@ const char* hvs_last_error(const hvs_ctx* c) { return c ? c->err.c_str() : "hvs:
 int hvs_set_engine(hvs_ctx* c, int engine)
 {
     if (!c) return HVS_EINVAL;
-    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN)
-        return fail(c, HVS_EINVAL, "hvs_set_engine: engine not available in this build");
+    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER)
+        return fail(c, HVS_EINVAL, "hvs_set_engine: unknown engine");
     c->engine = engine;
+    if (c->d_data && !c->have_index && (engine == HVS_ENGINE_MFMA_FILTER || (engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows))) {
+        HVS_HIP(c, hipSetDevice(c->device));
+        return build_index(c);
+    }
     return HVS_OK;
 }
 
@@ -325,6 +581,26 @@ static int begin_data(hvs_ctx* c, uint32_t n)
     return dev_alloc(c, &c->d_data, (size_t)n * HVS_DCOLS);
 }
 
+// upload/generation is timed by ev_q0..ev_q1; the index build (sort + BF16 tiles) follows
+static int finish_data(hvs_ctx* c)
+{
+    float ms = 0.f;
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->load_ms = ms;
+    free_index(c);
+    if (c->engine == HVS_ENGINE_EXACT_SCAN) return HVS_OK;
+    if (c->engine == HVS_ENGINE_AUTO && c->n < kMfmaMinRows) return HVS_OK;
+    HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
+    int rc = build_index(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->index_ms = ms;
+    c->load_ms += ms;
+    return HVS_OK;
+}
+
 int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
 {
     if (!c) return HVS_EINVAL;
@@ -336,11 +612,8 @@ int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
                               c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
-    c->load_ms = ms;
     c->n = n;
-    return HVS_OK;
+    return finish_data(c);
 }
 
 int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
@@ -355,11 +628,8 @@ int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t nc
     HVS_HIP(c, hipGetLastError());
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
-    c->load_ms = ms;
     c->n = n;
-    return HVS_OK;
+    return finish_data(c);
 }
 
 int hvs_download_data(hvs_ctx* c, uint32_t row0, uint32_t nrows, float* out_rows)
@@ -492,7 +762,7 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
     }
     c->timing.main_kernel_ms = k;
     c->timing.main_kernel_launches = (uint32_t)c->n_launch_events;
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HVS_HIP(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->timing.pairs = h[0];
     c->timing.scanned_pairs = h[1];

@@ -1,0 +1,777 @@
+// hvs_filter.h -- the MFMA engine: BF16 matrix-core bound filter + exact-order re-scoring.
+//
+// Idea.  The reference evaluates 300 non-fusable f32 operations for every (query,row) pair that
+// passes the predicate (optimized_impl.h:96-125).  Only ~100 + O(100 log n) of those pairs can ever
+// enter a query's top-100.  This engine proves, with a cheap BF16 matrix-core product and a rigorous
+// error bound, that almost every pair CANNOT enter the top-100 and runs the exact-order kernel only
+// on the few survivors.  Membership and order of the answer are always decided by exact-order f32
+// distances, never by the BF16 value, so the output is bit-identical to the exact engine's.
+//
+// Index (built once per data set, "it is prohibitive to use query vectors during indexing" --
+// reference README.md:68 -- is respected: only D is used):
+//   * two orderings of the rows: by (C,T) and by T.  Every predicate of the reference
+//     (optimized_parallel.hpp:105-138) is then a contiguous POSITION RANGE: type 0 = everything,
+//     type 1 = the C==v run, type 3 = the T-window inside that run, type 2 = a T-window of the
+//     T ordering.  Ranges come from integer binary searches on order-preserving keys.
+//   * each ordering is cut into blocks of 32 consecutive positions, stored as BF16 MFMA A-operand
+//     fragments (K padded 100 -> 112; k = 100..102 hold -|d|^2/2 split into three BF16 pieces so
+//     that one MFMA chain yields  s = q.d - |d|^2/2  directly).
+//   * blocks are stored LEVEL-INTERLEAVED: level 0 = every 4^K-th block, level j = multiples of
+//     4^(K-j) not in an earlier level, last level = the remaining 3/4.  Any position range meets
+//     every level in one contiguous storage run, and level j multiplies the rows a query has seen
+//     by ~4.  A query's threshold tau therefore tightens geometrically and each round hands only
+//     ~300 (+ error band) candidates per query to the exact kernel, whatever the range.
+//
+// Per batch of queries:  prep (ranges, BF16 B-fragments, norms) -> level 0 by the exact kernel
+// -> merge -> for each further level { MFMA filter -> exact re-score of survivors -> merge }
+// -> pad + sort + write.  A query whose candidate list overflows is re-run by the exact engine.
+#pragma once
+
+#include "hvs_device.h"
+
+#define HVS_KPAD 112          // padded contraction length (7 MFMA k-steps of 16)
+#define HVS_KSTEPS 7
+#define HVS_TILE_U4 (HVS_KSTEPS * 64)  // uint4 per 32-row tile (7 KiB)
+#define HVS_QB 4              // query blocks (of 32) per wave in the filter kernel
+#define HVS_GROUP (32 * HVS_QB)
+#define HVS_FCAP 1024         // per-query candidate keys per round
+#define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
+#define HVS_SEG 128           // row blocks per filter work item
+#define HVS_TOPCAP 128        // stored top list stride
+
+typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hvs_f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// order-preserving integer keys of f32 attributes.  -0 is folded into +0 (they compare equal in
+// every predicate), NaN maps to the largest key (it fails every comparison of the reference and
+// must stay outside every non-trivial range).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t hvs_attr_key(float f)
+{
+    if (f != f) return 0xFFFFFFFFu;
+    if (f == 0.0f) f = 0.0f;  // -0 -> +0
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t u = __float_as_uint(f);
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+#define HVS_KEY_POS_INF 0xFF800000u  // hvs_attr_key(+inf): upper bound of every non-NaN value
+
+__device__ __forceinline__ uint16_t hvs_bf16_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // round to nearest even
+}
+__device__ __forceinline__ float hvs_bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+__device__ __forceinline__ float hvs_round_up_f32(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);  // x > 0 here
+    return f;
+}
+
+__device__ __forceinline__ void hvs_atomic_max_pos(float* addr, float v)  // v >= 0
+{
+    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// ---------------------------------------------------------------------------------------------
+// level arithmetic (see header comment).  g4(t) = #{u in [0,t) : u % 4 != 0}.
+// ---------------------------------------------------------------------------------------------
+struct HvsLevels {
+    uint32_t K;             // last level index
+    uint32_t nblk;          // blocks in the ordering
+    uint32_t off[16];       // storage offset of each level; off[K+1] = nblk
+};
+
+__host__ __device__ static inline uint32_t hvs_g4(uint32_t t) { return t - (t + 3u) / 4u; }
+__host__ __device__ static inline uint32_t hvs_ceil_div(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+// storage run [lo,hi) (absolute storage indices) of level j inside block range [blo,bhi)
+__host__ __device__ static inline void hvs_level_run(const HvsLevels& L, uint32_t j, uint32_t blo, uint32_t bhi,
+                                                    uint32_t& lo, uint32_t& hi)
+{
+    if (bhi <= blo) {
+        lo = hi = 0;
+        return;
+    }
+    const uint32_t s = 1u << (2u * (L.K - j));
+    const uint32_t tlo = hvs_ceil_div(blo, s), thi = hvs_ceil_div(bhi, s);
+    if (j == 0) {
+        lo = L.off[0] + tlo;
+        hi = L.off[0] + thi;
+    } else {
+        lo = L.off[j] + hvs_g4(tlo);
+        hi = L.off[j] + hvs_g4(thi);
+    }
+}
+
+// storage index -> source block
+__host__ __device__ static inline uint32_t hvs_storage_to_block(const HvsLevels& L, uint32_t idx)
+{
+    uint32_t j = 0;
+    while (j < L.K && idx >= L.off[j + 1]) ++j;
+    const uint32_t i = idx - L.off[j];
+    const uint32_t s = 1u << (2u * (L.K - j));
+    if (j == 0) return i * s;
+    return (i + i / 3u + 1u) * s;  // the i-th positive integer that is not a multiple of 4
+}
+
+// ---------------------------------------------------------------------------------------------
+// Index build
+// ---------------------------------------------------------------------------------------------
+__global__ void hvs_k_attr_keys(const float* __restrict__ D, uint32_t n, uint64_t* __restrict__ keys_ct,
+                                uint64_t* __restrict__ keys_t, uint32_t* __restrict__ ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t kc = hvs_attr_key(D[(size_t)i * HVS_DCOLS]);
+    const uint32_t kt = hvs_attr_key(D[(size_t)i * HVS_DCOLS + 1]);
+    keys_ct[i] = ((uint64_t)kc << 32) | kt;
+    keys_t[i] = ((uint64_t)kt << 32) | i;  // full 64-bit sort; the row id only breaks ties
+    ids[i] = i;
+}
+
+struct HvsBounds {  // global maxima over rows, all rounded up
+    float e_d;    // max |d - bf16(d)|_2
+    float nb_d;   // max |bf16(d)|_2
+    float hmax;   // max |d|^2 / 2
+    float rho;    // max | |d|^2/2 + (h0+h1+h2) |
+};
+
+// one wave per storage block: builds the 7 KiB A-operand tile and the row bounds
+__global__ __launch_bounds__(256) void hvs_k_build_tiles(const float* __restrict__ D, uint32_t n,
+                                                         const uint32_t* __restrict__ perm, HvsLevels L,
+                                                         uint4* __restrict__ tiles, uint32_t* __restrict__ blockpos,
+                                                         HvsBounds* __restrict__ bounds)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= L.nblk) return;
+    const uint32_t b = hvs_storage_to_block(L, idx);
+    if (lane == 0u) blockpos[idx] = b;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t pos = b * 32u + r;
+    const bool valid = pos < n;
+    const float* __restrict__ row = D + (size_t)(valid ? perm[pos] : 0u) * HVS_DCOLS + 2;
+
+    double nd = 0.0, e2 = 0.0, nb2 = 0.0;
+    for (int k = 0; k < HVS_NDIM; ++k) {
+        const float x = row[k];
+        const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+        nd += (double)x * (double)x;
+        e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
+        nb2 += (double)xb * (double)xb;
+    }
+    // h = -|d|^2/2 as three BF16 pieces; invalid (padding) rows get a huge negative bias
+    float hf = valid ? (float)(-0.5 * nd) : -1.0e30f;
+    const uint16_t h0 = hvs_bf16_bits(hf);
+    const float r1 = valid ? hf - hvs_bf16_to_f32(h0) : 0.0f;
+    const uint16_t h1 = hvs_bf16_bits(r1);
+    const float r2 = r1 - hvs_bf16_to_f32(h1);
+    const uint16_t h2 = hvs_bf16_bits(r2);
+    if (valid && h == 0u) {
+        const double hs = (double)hvs_bf16_to_f32(h0) + (double)hvs_bf16_to_f32(h1) + (double)hvs_bf16_to_f32(h2);
+        hvs_atomic_max_pos(&bounds->e_d, hvs_round_up_f32(sqrt(e2)));
+        hvs_atomic_max_pos(&bounds->nb_d, hvs_round_up_f32(sqrt(nb2)));
+        hvs_atomic_max_pos(&bounds->hmax, hvs_round_up_f32(0.5 * nd));
+        hvs_atomic_max_pos(&bounds->rho, hvs_round_up_f32(fabs(0.5 * nd + hs) + 1e-30));
+    }
+#pragma unroll
+    for (int s = 0; s < HVS_KSTEPS; ++s) {
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint16_t lo16, hi16;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 16 * s + 8 * (int)h + 2 * p + e;
+                uint16_t v;
+                if (k < HVS_NDIM)
+                    v = valid ? hvs_bf16_bits(row[k]) : (uint16_t)0;
+                else if (k == 100)
+                    v = h0;
+                else if (k == 101)
+                    v = h1;
+                else if (k == 102)
+                    v = h2;
+                else
+                    v = 0;
+                if (e == 0)
+                    lo16 = v;
+                else
+                    hi16 = v;
+            }
+            w[p] = (uint32_t)lo16 | ((uint32_t)hi16 << 16);
+        }
+        tiles[((size_t)idx * HVS_KSTEPS + s) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-batch query state (structure of arrays over PADDED SLOTS; slot = block*32 + i)
+// ---------------------------------------------------------------------------------------------
+struct HvsBatch {
+    // layout of the batch
+    uint32_t nslots;            // padded slots (multiple of HVS_GROUP)
+    uint32_t ngroups;           // nslots / HVS_GROUP
+    uint32_t* qid;              // [nslots] original query index or 0xFFFFFFFF
+    uint32_t* rank;             // [nslots] predicate class: 0,1,2(type 3),3(invalid),4(type 2 -> T ordering)
+    uint32_t* ra;               // [nslots] own position range [ra, rb)
+    uint32_t* rb;
+    uint32_t* gua;              // [ngroups] union range of the group
+    uint32_t* gub;
+    uint32_t* gord;             // [ngroups] ordering used by the group: 0 = (C,T), 1 = T
+    // filter operands
+    uint4* bfrag;               // [nslots/32][7][64] BF16 B-operand fragments
+    float* theta;               // [nslots]
+    double* qn;                 // [nslots] |q|^2
+    float* normq;               // [nslots] |q| (rounded up)
+    float* eq;                  // [nslots] |q - bf16(q)| (rounded up)
+    float* nqb;                 // [nslots] |bf16(q)| (rounded up)
+    // top-k state
+    uint64_t* top;              // [nslots][HVS_TOPCAP]
+    uint32_t* topcnt;           // [nslots]
+    float* tau;                 // [nslots]
+    uint64_t* cand;             // [nslots][HVS_FCAP]
+    uint32_t* candcnt;          // [nslots]
+    uint32_t* overflow;         // [nslots]
+    // filter output
+    uint64_t* pairs;            // [ngroups][HVS_GCAP]  (slot << 32 | pos)
+    uint32_t* paircnt;          // [ngroups]
+    uint32_t* goverflow;        // [ngroups]
+};
+
+// class rank of a query type: (C,T)-ordering classes first, the T-ordering class (type 2) last
+__device__ __forceinline__ uint32_t hvs_type_rank(uint32_t type)
+{
+    return type == 0u ? 0u : type == 1u ? 1u : type == 3u ? 2u : type == 2u ? 4u : 3u;
+}
+
+// sort key of a query inside a batch: rank:3 | key(v):32 | key(l) >> 3
+__global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint64_t* __restrict__ keys,
+                                  uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
+    const uint32_t rk = hvs_type_rank(p.type);
+    const uint32_t vk = (p.type == 1u || p.type == 3u) ? hvs_attr_key(p.vf) : 0u;
+    const uint32_t lk = (p.type == 2u || p.type == 3u) ? hvs_attr_key(p.l) : 0u;
+    keys[i] = ((uint64_t)rk << 61) | ((uint64_t)vk << 29) | (uint64_t)(lk >> 3);
+    idx[i] = q0 + i;
+}
+
+// Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole group,
+// the type-2 part padded to a whole group.  One thread block; writes the slot -> query map.
+// layout[0..4] = first slot of each class rank, layout[5] = nslots used, layout[6] = first group of T part
+__global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
+                             uint32_t nq, uint32_t nslots_cap, uint32_t* __restrict__ qid, uint32_t* __restrict__ rank,
+                             uint32_t* __restrict__ layout)
+{
+    __shared__ uint32_t first[6];   // first sorted index of each rank (first[5] = nq)
+    __shared__ uint32_t slot0[6];
+    if (threadIdx.x < 6u) {
+        const uint32_t rk = threadIdx.x;
+        uint32_t lo = 0, hi = nq;  // first index with (key >> 61) >= rk
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)(sorted_keys[mid] >> 61) < rk) lo = mid + 1; else hi = mid;
+        }
+        first[rk] = rk == 5u ? nq : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t s = 0;
+        for (uint32_t rk = 0; rk < 5u; ++rk) {
+            if (rk == 4u) s = hvs_ceil_div(s, HVS_GROUP) * HVS_GROUP;  // T-ordering part starts a new group
+            slot0[rk] = s;
+            const uint32_t cnt = first[rk + 1] - first[rk];
+            s += hvs_ceil_div(cnt, 32u) * 32u;
+        }
+        slot0[5] = hvs_ceil_div(s, HVS_GROUP) * HVS_GROUP;
+        for (uint32_t rk = 0; rk < 5u; ++rk) layout[rk] = slot0[rk];
+        layout[5] = slot0[5];
+        layout[6] = slot0[4] / HVS_GROUP;
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < nslots_cap; s += blockDim.x) {
+        uint32_t rk = 0;
+        while (rk < 4u && s >= slot0[rk + 1]) ++rk;
+        const uint32_t off = s - slot0[rk];
+        const uint32_t cnt = first[rk + 1] - first[rk];
+        const bool used = s < slot0[5] && off < cnt;
+        qid[s] = used ? sorted_idx[first[rk] + off] : 0xFFFFFFFFu;
+        rank[s] = rk;
+    }
+}
+
+__device__ __forceinline__ uint32_t hvs_lower_bound64(const uint64_t* __restrict__ a, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;  // first index with a[i] >= key
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// per slot: position range of the predicate, norms, bound inputs; resets the top-k state
+__global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
+                                 const uint64_t* __restrict__ keys_t, uint32_t n,
+                                 unsigned long long* __restrict__ counters)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B.nslots) return;
+    const uint32_t qi = B.qid[s];
+    uint32_t a = 0, b = 0;
+    double qn = 0.0, e2 = 0.0, nb2 = 0.0;
+    if (qi != 0xFFFFFFFFu) {
+        const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
+        const HvsQParams p = hvs_parse_query(q);
+        const uint32_t kv = hvs_attr_key(p.vf), kl = hvs_attr_key(p.l), kr = hvs_attr_key(p.r);
+        const bool lr_ok = (p.l == p.l) && (p.r == p.r);  // NaN bounds match nothing
+        if (p.type == 0u) {
+            a = 0;
+            b = n;
+        } else if (p.type == 1u) {
+            a = hvs_lower_bound64(keys_ct, n, (uint64_t)kv << 32);
+            b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv + 1ull) << 32);  // rows with T = NaN still match C==v
+        } else if (p.type == 3u && lr_ok && kl <= kr) {
+            a = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | kl);
+            b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | ((uint64_t)kr + 1ull));
+        } else if (p.type == 2u && lr_ok && kl <= kr) {
+            a = hvs_lower_bound64(keys_t, n, (uint64_t)kl << 32);
+            b = hvs_lower_bound64(keys_t, n, ((uint64_t)kr + 1ull) << 32);
+        }
+        if (b < a) b = a;
+        for (int k = 0; k < HVS_NDIM; ++k) {
+            const float x = q[4 + k];
+            const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+            qn += (double)x * (double)x;
+            e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
+            nb2 += (double)xb * (double)xb;
+        }
+        atomicAdd(&counters[0], (unsigned long long)(b - a));
+    }
+    B.ra[s] = a;
+    B.rb[s] = b;
+    B.qn[s] = qn;
+    B.normq[s] = hvs_round_up_f32(sqrt(qn) + 1e-30);
+    B.eq[s] = hvs_round_up_f32(sqrt(e2) + 1e-30);
+    B.nqb[s] = hvs_round_up_f32(sqrt(nb2) + 1e-30);
+    B.topcnt[s] = 0;
+    B.candcnt[s] = 0;
+    B.overflow[s] = 0;
+    B.tau[s] = __builtin_inff();
+    // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
+    B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
+}
+
+// per group: union of the slots' ranges, ordering; per block: BF16 B-operand fragments.
+// One 128-thread block per group.
+__global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __restrict__ Q, HvsBatch B)
+{
+    __shared__ uint32_t smin[HVS_GROUP], smax[HVS_GROUP];
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t s = g * HVS_GROUP + t;
+    const uint32_t a = B.ra[s], b = B.rb[s];
+    smin[t] = a < b ? a : 0xFFFFFFFFu;
+    smax[t] = a < b ? b : 0u;
+    __syncthreads();
+    for (uint32_t w = HVS_GROUP / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            smin[t] = smin[t] < smin[t + w] ? smin[t] : smin[t + w];
+            smax[t] = smax[t] > smax[t + w] ? smax[t] : smax[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0u) {
+        const bool any = smin[0] < smax[0];
+        B.gua[g] = any ? smin[0] : 0u;
+        B.gub[g] = any ? smax[0] : 0u;
+        B.gord[g] = B.rank[g * HVS_GROUP] == 4u ? 1u : 0u;
+        B.paircnt[g] = 0;
+        B.goverflow[g] = 0;
+    }
+    // B fragments: lane l of k-step ks holds query column (l & 31), k = 16 ks + 8 (l >> 5) + 0..7
+    for (uint32_t e = t; e < HVS_QB * HVS_KSTEPS * 64u; e += HVS_GROUP) {
+        const uint32_t qb = e / (HVS_KSTEPS * 64u);
+        const uint32_t ks = (e / 64u) % HVS_KSTEPS;
+        const uint32_t l = e & 63u;
+        const uint32_t slot = g * HVS_GROUP + qb * 32u + (l & 31u);
+        const uint32_t qi = B.qid[slot];
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint16_t v2[2];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int k = 16 * (int)ks + 8 * (int)(l >> 5) + 2 * p + e2;
+                uint16_t v = 0;
+                if (qi != 0xFFFFFFFFu) {
+                    if (k < HVS_NDIM)
+                        v = hvs_bf16_bits(Q[(size_t)qi * HVS_QCOLS + 4 + k]);
+                    else if (k < 103)
+                        v = 0x3F80;  // 1.0: multiplies the three -|d|^2/2 pieces
+                }
+                v2[e2] = v;
+            }
+            w[p] = (uint32_t)v2[0] | ((uint32_t)v2[1] << 16);
+        }
+        B.bfrag[((size_t)(g * HVS_QB + qb) * HVS_KSTEPS + ks) * 64u + l] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_seed_exact -- level 0 by the exact kernel (lane = query, wave-uniform rows through the
+// scalar cache, exactly like hvs_k_scan_exact) over the level-0 blocks of the group's range.
+// The per-lane predicate is the slot's own position range.  Survivors go to cand[slot].
+// One wave per 64 slots.
+// ---------------------------------------------------------------------------------------------
+struct HvsUniformRowF2 {
+    const hvs_f2* __restrict__ p;
+    __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
+};
+
+__global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restrict__ D, uint32_t n,
+                                                           const float* __restrict__ Q, HvsBatch B,
+                                                           const uint32_t* __restrict__ perm_ct,
+                                                           const uint32_t* __restrict__ perm_t,
+                                                           const uint32_t* __restrict__ bpos_ct,
+                                                           const uint32_t* __restrict__ bpos_t, HvsLevels L,
+                                                           unsigned long long* __restrict__ counters)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = w * 64u + lane;
+    if (w * 64u >= B.nslots) return;
+    const uint32_t g = (w * 64u) / HVS_GROUP;
+    const uint32_t ord = B.gord[g];
+    const uint32_t* __restrict__ perm = ord ? perm_t : perm_ct;
+    const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
+    const uint32_t ua = B.gua[g], ub = B.gub[g];
+    uint32_t lo, hi;
+    hvs_level_run(L, 0, ua / 32u, hvs_ceil_div(ub, 32u), lo, hi);
+    if (lo >= hi) return;
+
+    const uint32_t qi = B.qid[slot];
+    const bool have_q = qi != 0xFFFFFFFFu;
+    const float* __restrict__ qrow = Q + (size_t)(have_q ? qi : 0u) * HVS_QCOLS;
+    const uint32_t ra = have_q ? B.ra[slot] : 0u, rb = have_q ? B.rb[slot] : 0u;
+    hvs_f2 q2[HVS_NDIM / 2];
+#pragma unroll
+    for (int i = 0; i < HVS_NDIM / 4; ++i) {
+        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 4 * i);
+        q2[2 * i] = hvs_f2{v4.x, v4.y};
+        q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
+    }
+    uint64_t* __restrict__ mylist = B.cand + (size_t)slot * HVS_FCAP;
+    float tau = __builtin_inff();
+    uint32_t cnt = 0, nscan = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t b = bpos[i];
+        for (uint32_t r = 0; r < 32u; ++r) {
+            const uint32_t pos = b * 32u + r;
+            if (pos >= n) break;
+            const bool pass = pos >= ra && pos < rb;
+            if (__ballot(pass) == 0ull) continue;
+            nscan += 64u;
+            const uint32_t id = perm[pos];
+            HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(D + (size_t)id * HVS_DCOLS + 2)};
+            const float dist = hvs_exact_dist_pk(dv, q2);
+            if (pass && dist <= tau) {
+                mylist[cnt] = hvs_make_key(dist, id);
+                ++cnt;
+            }
+            uint64_t full = __ballot(cnt == 256u);
+            if (full != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                while (full != 0ull) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(full);
+                    full &= full - 1ull;
+                    uint64_t* lst = B.cand + (size_t)(w * 64u + l) * HVS_FCAP;
+                    const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, 256u, lane);
+                    if (lane == l) {
+                        cnt = HVS_KNN;
+                        tau = hvs_key_dist(kth);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+    }
+    B.candcnt[slot] = cnt;
+    if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nscan);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_filter_mfma -- the dominant kernel.
+//
+// Work item = (group of 4 query blocks = 128 queries, one level, one segment of <= HVS_SEG row
+// blocks of the group's storage run).  One wave per item, 4 items (consecutive groups, same
+// segment index) per 256-thread workgroup so that waves streaming the same tiles share L1/L2.
+//
+// Per row block: 7 x global_load_dwordx4 fetch the A fragments (1 KiB per instruction, lane-linear,
+// perfectly coalesced); for each of the wave's 4 resident query blocks a chain of 7
+// v_mfma_f32_32x32x16_bf16 yields  s[row][query] = q.d - |d|^2/2 ; the 16 accumulators of a lane
+// belong to ONE query (the lane's column), so the test "could this row still enter the query's
+// top-100"  s >= theta[query]  needs one v_max3 tree and one compare against a per-lane constant.
+// Rare survivors are range-checked, packed as (slot << 32 | position) into a wave-private LDS
+// buffer and flushed to the group's pair list with one returning atomic per ~200 pairs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ hvs_bf16x8 hvs_as_bf16x8(const uint4& u)
+{
+    union {
+        uint4 u4;
+        hvs_bf16x8 b8;
+    } c;
+    c.u4 = u;
+    return c.b8;
+}
+
+__global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restrict__ tiles_ct,
+                                                            const uint4* __restrict__ tiles_t,
+                                                            const uint32_t* __restrict__ bpos_ct,
+                                                            const uint32_t* __restrict__ bpos_t, HvsLevels L,
+                                                            uint32_t level, HvsBatch B,
+                                                            unsigned long long* __restrict__ counters)
+{
+    __shared__ uint64_t sbuf[4][256];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.y * 4u + wv;
+    if (g >= B.ngroups) return;
+    const uint32_t ord = B.gord[g];
+    if (level > L.K) return;
+    const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
+    const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
+    uint32_t lo, hi;
+    hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
+    // segments are aligned to absolute storage indices so that neighbouring groups share tiles
+    const uint32_t seg_lo = (lo / HVS_SEG + blockIdx.x) * HVS_SEG;
+    if (seg_lo >= hi) return;
+    const uint32_t i0 = seg_lo > lo ? seg_lo : lo;
+    const uint32_t i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+
+    // resident query operands
+    hvs_bf16x8 bq[HVS_QB][HVS_KSTEPS];
+    float theta[HVS_QB];
+    uint32_t ra[HVS_QB], rb[HVS_QB];
+#pragma unroll
+    for (int qb = 0; qb < HVS_QB; ++qb) {
+        const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+        theta[qb] = B.theta[slot];
+        ra[qb] = B.ra[slot];
+        rb[qb] = B.rb[slot];
+#pragma unroll
+        for (int ks = 0; ks < HVS_KSTEPS; ++ks)
+            bq[qb][ks] = hvs_as_bf16x8(B.bfrag[((size_t)(g * HVS_QB + qb) * HVS_KSTEPS + ks) * 64u + lane]);
+    }
+    uint64_t* __restrict__ lbuf = sbuf[wv];
+    uint32_t wcnt = 0;  // wave-uniform fill of lbuf
+    uint32_t nblocks = 0;
+
+    auto flush = [&]() {
+        if (wcnt == 0u) return;
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(&B.paircnt[g], wcnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (base + wcnt <= HVS_GCAP) {
+            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * HVS_GCAP + base + e] = lbuf[e];
+        } else if (lane == 0u) {
+            B.goverflow[g] = 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        wcnt = 0;
+    };
+
+    for (uint32_t i = i0; i < i1; ++i) {
+        hvs_bf16x8 af[HVS_KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(tiles[((size_t)i * HVS_KSTEPS + ks) * 64u + lane]);
+        const uint32_t bp = bpos[i];
+        ++nblocks;
+#pragma unroll
+        for (int qb = 0; qb < HVS_QB; ++qb) {
+            hvs_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < HVS_KSTEPS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc, 0, 0, 0);
+            float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+            m = fmaxf(m, acc[15]);
+            const bool hit = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
+            if (__ballot(hit) != 0ull) {
+                const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+                    const bool c = acc[r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
+                    const uint64_t mask = __ballot(c);
+                    if (mask != 0ull) {
+                        if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
+                        wcnt += (uint32_t)__popcll(mask);
+                        if (wcnt > 192u) flush();
+                    }
+                }
+            }
+        }
+    }
+    flush();
+    if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_rescore -- exact-order distances of the filter's survivors: one lane per (slot,pos) pair,
+// the same arithmetic as everywhere else (hvs_exact_dist), key appended to the slot's list.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvs_k_rescore(const float* __restrict__ D, const float* __restrict__ Q, HvsBatch B,
+                                                     const uint32_t* __restrict__ perm_ct,
+                                                     const uint32_t* __restrict__ perm_t,
+                                                     unsigned long long* __restrict__ counters)
+{
+    const uint32_t g = blockIdx.y;
+    uint32_t np = B.paircnt[g];
+    if (np > HVS_GCAP) np = HVS_GCAP;
+    const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
+        const uint64_t pr = B.pairs[(size_t)g * HVS_GCAP + e];
+        const uint32_t slot = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
+        const uint32_t id = perm[pos];
+        const uint32_t qi = B.qid[slot];
+        const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
+        const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
+        const float dist = hvs_exact_dist(dv, qv);
+        if (dist <= B.tau[slot]) {
+            const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
+            if (k < HVS_FCAP)
+                B.cand[(size_t)slot * HVS_FCAP + k] = hvs_make_key(dist, id);
+            else
+                B.overflow[slot] = 1u;
+        }
+    }
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        atomicAdd(&counters[2], (unsigned long long)np);
+        if (B.goverflow[g]) {
+            for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_merge -- per slot (one wave): top-100 := 100 smallest keys of (top U cand); new tau and
+// the filter threshold theta for the next level.  With `final` it also pads from the end of D
+// (optimized_parallel.hpp:149-157), rank-sorts and writes the answer at the query's own index.
+//
+// theta: a row can be discarded when its exact-order distance R is certainly > tau.
+//   R >= T (1 - g), T = |q-d|^2 (real), g = 20 * 2^-24 (f32 roundings of the reference order)
+//   T >= |q|^2 - 2 s~ - 2 (mu + rho + |q| E_D + e_q NB_D)
+//        s~  = MFMA value of  bf16(q).bf16(d) + h0+h1+h2,     h ~ -|d|^2/2
+//        mu  = bound on the MFMA accumulation error, rho = |  |d|^2/2 + h0+h1+h2 |
+//        |q.d - bf16(q).bf16(d)| <= |q| E_D + e_q NB_D   (Cauchy-Schwarz; E_D, NB_D row maxima)
+//   => discard iff  s~ < theta := (|q|^2 - tau (1 + 2g)) / 2 - (mu + rho + |q| E_D + e_q NB_D) - slack
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
+                                                   HvsBatch B, const HvsBounds* __restrict__ bounds, int final,
+                                                   uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+{
+    __shared__ uint64_t sbuf[4][256];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * 4u + w;
+    if (slot >= B.nslots) return;
+    const uint32_t qi = B.qid[slot];
+    if (qi == 0xFFFFFFFFu) return;
+    uint64_t* buf = sbuf[w];
+    uint32_t cnt = B.topcnt[slot];
+    for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * HVS_TOPCAP + e];
+    uint32_t m = B.candcnt[slot];
+    if (m > HVS_FCAP) m = HVS_FCAP;
+    const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
+    for (uint32_t off = 0; off < m; off += 64u) {
+        if (cnt + 64u > 256u) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+            cnt = HVS_KNN;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        const uint32_t take = (m - off) < 64u ? (m - off) : 64u;
+        if (lane < take) buf[cnt + lane] = lst[off + lane];
+        cnt += take;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (cnt > HVS_KNN) {
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        cnt = HVS_KNN;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    if (!final) {
+        for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * HVS_TOPCAP + e] = buf[e];
+        // tau = largest kept distance once 100 are held
+        float dmax = 0.0f;
+        for (uint32_t e = lane; e < cnt; e += 64u) dmax = fmaxf(dmax, hvs_key_dist(buf[e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        if (lane == 0u) {
+            B.topcnt[slot] = cnt;
+            B.candcnt[slot] = 0;
+            float tau = __builtin_inff();
+            float theta = B.rb[slot] > B.ra[slot] ? -__builtin_inff() : __builtin_inff();
+            if (cnt >= HVS_KNN) {
+                tau = dmax;
+                const double g = 20.0 * 5.9604644775390625e-08;
+                const double sabs = (double)B.nqb[slot] * (double)bounds->nb_d + 1.02 * (double)bounds->hmax;
+                const double mu = 256.0 * 5.9604644775390625e-08 * sabs;
+                const double band = mu + (double)bounds->rho + (double)B.normq[slot] * (double)bounds->e_d +
+                                    (double)B.eq[slot] * (double)bounds->nb_d;
+                const double th = 0.5 * (B.qn[slot] * (1.0 - 1e-12) - (double)tau * (1.0 + 2.0 * g)) - band * (1.0 + 1e-6) - 1e-3;
+                float tf = (float)th;
+                if ((double)tf > th) {  // round down
+                    if (tf == 0.0f) tf = -1.0e-30f;
+                    else tf = __uint_as_float(__float_as_uint(tf) + (tf < 0.0f ? 1u : 0xFFFFFFFFu));
+                }
+                theta = tf;
+            }
+            B.tau[slot] = tau;
+            B.theta[slot] = theta;
+        }
+        return;
+    }
+    // ---- final: pad, rank-sort, write
+    const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
+    for (uint32_t base = cnt; base < HVS_KNN; base += 64u) {
+        const uint32_t e = base + lane;
+        if (e < HVS_KNN) {
+            const uint32_t id = n - 1u - (e - cnt);
+            const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
+            buf[e] = hvs_make_key(hvs_exact_dist(dv, qv), id);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+        const uint64_t ke = buf[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+            const uint64_t kj = buf[j];
+            rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
+        }
+        out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = hvs_key_dist(ke);
+    }
+}
+
+// queries whose candidate lists overflowed -> compact list for the exact engine
+__global__ void hvs_k_collect_overflow(HvsBatch B, uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B.nslots) return;
+    if (B.qid[s] != 0xFFFFFFFFu && B.overflow[s]) list[atomicAdd(count, 1u)] = B.qid[s];
+}
