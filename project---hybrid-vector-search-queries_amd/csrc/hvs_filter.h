@@ -267,8 +267,8 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     idx[i] = q0 + i;
 }
 
-// Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole group,
-// the type-2 part padded to a whole group.  One thread block; writes the slot -> query map.
+// Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole quad of
+// groups (a filter workgroup serves one quad and one ordering), the type-2 part to a whole group.  One thread block; writes the slot -> query map.
 // layout[0..4] = first slot of each class rank, layout[5] = nslots used, layout[6] = first group of T part
 __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
                              uint32_t nq, uint32_t nslots_cap, uint32_t* __restrict__ qid, uint32_t* __restrict__ rank,
@@ -289,7 +289,7 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
     if (threadIdx.x == 0u) {
         uint32_t s = 0;
         for (uint32_t rk = 0; rk < 5u; ++rk) {
-            if (rk == 4u) s = hvs_ceil_div(s, HVS_GROUP) * HVS_GROUP;  // T-ordering part starts a new group
+            if (rk == 4u) s = hvs_ceil_div(s, 4u * HVS_GROUP) * (4u * HVS_GROUP);  // T-ordering part starts a new QUAD of groups
             slot0[rk] = s;
             const uint32_t cnt = first[rk + 1] - first[rk];
             s += hvs_ceil_div(cnt, 32u) * 32u;
@@ -542,22 +542,45 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
                                                             uint32_t level, HvsBatch B,
                                                             unsigned long long* __restrict__ counters)
 {
-    __shared__ uint64_t sbuf[4][256];
+    __shared__ uint4 stile[2][HVS_TILE_U4];  // double-buffered A tile shared by the 4 waves (2 x 7 KiB)
+    __shared__ uint64_t sbuf[4][256];        // wave-private survivor buffers
+    __shared__ uint32_t srange[4][2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t g = blockIdx.y * 4u + wv;
-    if (g >= B.ngroups) return;
-    const uint32_t ord = B.gord[g];
-    if (level > L.K) return;
+    // grid: x = quad of groups (fastest), y = ABSOLUTE storage segment of the level.  Consecutive
+    // workgroups therefore stream the same 896 KiB of tiles for different queries, so a segment
+    // is fetched from HBM about once and then served by the XCDs' L2s / the Infinity Cache.
+    // The quad's 4 waves walk the segment together: every tile is fetched once per workgroup
+    // into LDS and read from there by all 4 waves (ds_read_b128).  All groups of a quad use the
+    // same ordering (the T-ordering part of a batch starts at a quad boundary).
+    const uint32_t g = blockIdx.x * 4u + wv;
+    const uint32_t gq = blockIdx.x * 4u;  // first group of the quad decides the ordering
+    const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
-    uint32_t lo, hi;
-    hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
-    // segments are aligned to absolute storage indices so that neighbouring groups share tiles
-    const uint32_t seg_lo = (lo / HVS_SEG + blockIdx.x) * HVS_SEG;
-    if (seg_lo >= hi) return;
-    const uint32_t i0 = seg_lo > lo ? seg_lo : lo;
-    const uint32_t i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
+    uint32_t i0 = 0, i1 = 0;  // this wave's tiles [i0,i1) inside the segment (empty when i0 >= i1)
+    if (g < B.ngroups && B.gord[g] == ord) {
+        uint32_t lo, hi;
+        hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
+        if (seg_lo < hi && seg_lo + HVS_SEG > lo) {
+            i0 = seg_lo > lo ? seg_lo : lo;
+            i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+        }
+    }
+    if (lane == 0u) {
+        srange[wv][0] = i0 < i1 ? i0 : 0xFFFFFFFFu;
+        srange[wv][1] = i0 < i1 ? i1 : 0u;
+    }
+    __syncthreads();
+    uint32_t I0 = srange[0][0], I1 = srange[0][1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        I0 = srange[w][0] < I0 ? srange[w][0] : I0;
+        I1 = srange[w][1] > I1 ? srange[w][1] : I1;
+    }
+    if (I0 >= I1) return;  // uniform over the workgroup
+    const bool active = i0 < i1;
 
     // resident query operands
     hvs_bf16x8 bq[HVS_QB][HVS_KSTEPS];
@@ -565,13 +588,13 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
     uint32_t ra[HVS_QB], rb[HVS_QB];
 #pragma unroll
     for (int qb = 0; qb < HVS_QB; ++qb) {
-        const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+        const uint32_t slot = (active ? g : gq) * HVS_GROUP + qb * 32u + (lane & 31u);
         theta[qb] = B.theta[slot];
         ra[qb] = B.ra[slot];
         rb[qb] = B.rb[slot];
 #pragma unroll
         for (int ks = 0; ks < HVS_KSTEPS; ++ks)
-            bq[qb][ks] = hvs_as_bf16x8(B.bfrag[((size_t)(g * HVS_QB + qb) * HVS_KSTEPS + ks) * 64u + lane]);
+            bq[qb][ks] = hvs_as_bf16x8(B.bfrag[((size_t)((active ? g : gq) * HVS_QB + qb) * HVS_KSTEPS + ks) * 64u + lane]);
     }
     uint64_t* __restrict__ lbuf = sbuf[wv];
     uint32_t wcnt = 0;  // wave-uniform fill of lbuf
@@ -592,41 +615,86 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
         wcnt = 0;
     };
 
-    for (uint32_t i = i0; i < i1; ++i) {
-        hvs_bf16x8 af[HVS_KSTEPS];
+    // stage tile I0, then: prefetch tile i+1 into registers, multiply tile i out of LDS, store the
+    // prefetched tile into the other LDS buffer, one barrier per tile.
+    const uint32_t t = threadIdx.x;
+    const bool second = t + 256u < HVS_TILE_U4;
+    uint4 v0 = tiles[(size_t)I0 * HVS_TILE_U4 + t];
+    uint4 v1 = second ? tiles[(size_t)I0 * HVS_TILE_U4 + t + 256u] : make_uint4(0, 0, 0, 0);
+    stile[0][t] = v0;
+    if (second) stile[0][t + 256u] = v1;
+    __syncthreads();
+    for (uint32_t i = I0; i < I1; ++i) {
+        const uint32_t cur = (i - I0) & 1u;
+        const bool more = i + 1u < I1;
+        if (more) {
+            v0 = tiles[(size_t)(i + 1u) * HVS_TILE_U4 + t];
+            if (second) v1 = tiles[(size_t)(i + 1u) * HVS_TILE_U4 + t + 256u];
+        }
+        if (active && i >= i0 && i < i1) {  // wave-uniform
+            const uint32_t bp = bpos[i];
+            ++nblocks;
+            hvs_bf16x8 af[HVS_KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(tiles[((size_t)i * HVS_KSTEPS + ks) * 64u + lane]);
-        const uint32_t bp = bpos[i];
-        ++nblocks;
+            for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(stile[cur][ks * 64 + lane]);
+            // four independent accumulation chains, then four epilogues: one scheduling region, so the
+            // v_max3 trees of one query block overlap the MFMAs of the next
+            hvs_f32x16 acc[HVS_QB];
+            bool hit[HVS_QB];
 #pragma unroll
-        for (int qb = 0; qb < HVS_QB; ++qb) {
-            hvs_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int qb = 0; qb < HVS_QB; ++qb) {
+                acc[qb] = hvs_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < HVS_KSTEPS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc, 0, 0, 0);
-            float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+                for (int ks = 0; ks < HVS_KSTEPS; ++ks)
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc[qb], 0, 0, 0);
+            }
+            bool anyhit = false;
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
-            m = fmaxf(m, acc[15]);
-            const bool hit = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
-            if (__ballot(hit) != 0ull) {
-                const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+            for (int qb = 0; qb < HVS_QB; ++qb) {
+                float m = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), acc[qb][2]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                    const bool c = acc[r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
-                    const uint64_t mask = __ballot(c);
-                    if (mask != 0ull) {
-                        if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
-                        wcnt += (uint32_t)__popcll(mask);
-                        if (wcnt > 192u) flush();
+                for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[qb][r]), acc[qb][r + 1]);
+                m = fmaxf(m, acc[qb][15]);
+                hit[qb] = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
+#ifdef HVS_EXPERIMENT_NOHIT
+                hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
+#endif
+                anyhit = anyhit || hit[qb];
+            }
+            if (__ballot(anyhit) != 0ull) {
+#pragma unroll
+                for (int qb = 0; qb < HVS_QB; ++qb) {
+                    if (__ballot(hit[qb]) == 0ull) continue;
+                    const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
+                        // and the append only run for the rare accumulator that beats the threshold
+                        const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
+                        if (m0 != 0ull) {
+                            const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+                            const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
+                            const uint64_t mask = __ballot(c);
+                            if (mask != 0ull) {
+                                if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
+                                wcnt += (uint32_t)__popcll(mask);
+                                if (wcnt > 192u) flush();
+                            }
+                        }
                     }
                 }
             }
         }
+        if (more) {
+            stile[cur ^ 1u][t] = v0;
+            if (second) stile[cur ^ 1u][t + 256u] = v1;
+        }
+        __syncthreads();
     }
-    flush();
-    if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
+    if (active) {
+        flush();
+        if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -640,7 +708,9 @@ __global__ __launch_bounds__(256) void hvs_k_rescore(const float* __restrict__ D
 {
     const uint32_t g = blockIdx.y;
     uint32_t np = B.paircnt[g];
-    if (np > HVS_GCAP) np = HVS_GCAP;
+    // a group whose pair list overflowed holds unwritten entries past the failed flush: none of
+    // its pairs are used, all of its queries are re-run by the exact engine
+    if (np > HVS_GCAP || B.goverflow[g]) np = 0;
     const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
         const uint64_t pr = B.pairs[(size_t)g * HVS_GCAP + e];

@@ -87,9 +87,10 @@ def library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB):
-        raise HvsError(-100, f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = C.CDLL(_LIB)
+    path = os.environ.get("HVS_LIB", _LIB)   # A/B experiments load an alternative build of the same ABI
+    if not os.path.exists(path):
+        raise HvsError(-100, f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
     vp = C.c_void_p
     sig = {
         "hvs_create": (C.c_int, [C.POINTER(vp), C.c_int]),
