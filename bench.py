@@ -95,7 +95,7 @@ def main():
 
     for b in range(a.warmup):
         step(b)
-    kern_ms, kern_launches, pairs, scanned, query_ms = 0.0, 0, 0, 0, 0.0
+    kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback = 0.0, 0, 0, 0, 0.0, 0, 0
     fence()
     t0 = time.perf_counter()
     for b in range(a.warmup, total_batches):
@@ -106,6 +106,8 @@ def main():
         pairs += tm.pairs
         scanned += tm.scanned_pairs
         query_ms += tm.query_ms
+        rescored += tm.rescored_pairs
+        fallback += tm.fallback_queries
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -147,7 +149,9 @@ def main():
                          "kernel_ms_avg": kern_ms / max(kern_launches, 1), "launches": kern_launches,
                          "pairs_per_launch": pairs / max(kern_launches, 1),
                          "evaluated_pairs_per_launch": scanned / max(kern_launches, 1),
-                         "device_query_ms_per_step": query_ms / a.steps},
+                         "device_query_ms_per_step": query_ms / a.steps,
+                         "rescored_pairs_per_query": rescored / max(a.batch * a.steps, 1),
+                         "fallback_queries": fallback},
             "load_s": load_s,
         }
 

@@ -51,6 +51,7 @@ typedef struct hvs_timing {
     double load_ms;       /* last hvs_load_data / hvs_gen_data: upload + index build                */
     uint32_t engine;      /* engine that ran                                                        */
     uint32_t fallback_queries; /* queries re-run by the exact scan after a filter overflow          */
+    uint64_t rescored_pairs;   /* MFMA engine: (query,row) pairs handed to the exact re-scoring kernel */
 } hvs_timing;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

@@ -229,24 +229,6 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
 // ---------------------------------------------------------------------------------------------
 // MFMA engine: index build
 // ---------------------------------------------------------------------------------------------
-HvsLevels make_levels(uint32_t n)
-{
-    HvsLevels L{};
-    L.nblk = (n + 31u) / 32u;
-    uint32_t K = 0;
-    while (K < 14u && (L.nblk >> (2u * (K + 1u))) >= 64u) ++K;  // level 0 keeps >= 64 blocks (2048 rows)
-    L.K = K;
-    uint32_t off = 0;
-    for (uint32_t j = 0; j <= K; ++j) {
-        L.off[j] = off;
-        const uint32_t s = 1u << (2u * (K - j));
-        const uint32_t t = hvs_ceil_div(L.nblk, s);
-        off += (j == 0) ? t : hvs_g4(t);
-    }
-    for (uint32_t j = K + 1; j < 16u; ++j) L.off[j] = off;
-    return L;
-}
-
 void free_index(hvs_ctx* c)
 {
     void* ptrs[] = {c->d_keys_ct, c->d_keys_t, c->d_perm_ct, c->d_perm_t, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t};
@@ -263,7 +245,7 @@ int build_index(hvs_ctx* c)
 {
     free_index(c);
     const uint32_t n = c->n;
-    const HvsLevels L = make_levels(n);
+    const HvsLevels L = hvs_make_levels(n);
     if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
     c->lv = L;
     int rc;
@@ -388,8 +370,10 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
     const HvsLevels L = c->lv;
     const uint32_t n = c->n;
 
-    hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys,
-                       c->d_qidx);
+    // ~2048 queries per start-position bin: inside a bin queries are ordered by range end
+    const uint32_t nbins = std::max(1u, std::min(4096u, nqb / 2048u));
+    hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys_ct,
+                       c->d_keys_t, n, nbins, c->d_keys, c->d_qidx);
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                          (size_t)nqb, 0, 64, c->stream));
@@ -766,6 +750,7 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
     HVS_HIP(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->timing.pairs = h[0];
     c->timing.scanned_pairs = h[1];
+    c->timing.rescored_pairs = h[2];
     *out = c->timing;
     return HVS_OK;
 }

@@ -16,11 +16,13 @@
 //   * each ordering is cut into blocks of 32 consecutive positions, stored as BF16 MFMA A-operand
 //     fragments (K padded 100 -> 112; k = 100..102 hold -|d|^2/2 split into three BF16 pieces so
 //     that one MFMA chain yields  s = q.d - |d|^2/2  directly).
-//   * blocks are stored LEVEL-INTERLEAVED: level 0 = every 4^K-th block, level j = multiples of
-//     4^(K-j) not in an earlier level, last level = the remaining 3/4.  Any position range meets
-//     every level in one contiguous storage run, and level j multiplies the rows a query has seen
-//     by ~4.  A query's threshold tau therefore tightens geometrically and each round hands only
-//     ~300 (+ error band) candidates per query to the exact kernel, whatever the range.
+//   * blocks are stored LEVEL-INTERLEAVED: level 0 = every S0-th block, level j = the multiples of
+//     stride[j] not in an earlier level (stride[j-1] = radix[j] * stride[j]; radix 4 for the early
+//     levels, 2 for the last three, which hold 1/8, 1/4 and 1/2 of the blocks).  Any position
+//     range meets every level in one contiguous storage run, and level j multiplies the rows a
+//     query has seen by radix[j].  A query's threshold tau therefore tightens geometrically and
+//     each round hands only ~100 (radix-1) (+ error band) candidates per query to the exact
+//     kernel, whatever the range.
 //
 // Per batch of queries:  prep (ranges, BF16 B-fragments, norms) -> level 0 by the exact kernel
 // -> merge -> for each further level { MFMA filter -> exact re-score of survivors -> merge }
@@ -37,6 +39,7 @@
 #define HVS_FCAP 1024         // per-query candidate keys per round
 #define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
 #define HVS_SEG 128           // row blocks per filter work item
+#define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage)
 #define HVS_TOPCAP 128        // stored top list stride
 
 typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
@@ -87,10 +90,13 @@ struct HvsLevels {
     uint32_t K;             // last level index
     uint32_t nblk;          // blocks in the ordering
     uint32_t off[16];       // storage offset of each level; off[K+1] = nblk
+    uint32_t stride[16];    // level j holds the multiples of stride[j] ...
+    uint32_t radix[16];     // ... that are not multiples of stride[j-1] = stride[j] * radix[j]  (j >= 1)
 };
 
-__host__ __device__ static inline uint32_t hvs_g4(uint32_t t) { return t - (t + 3u) / 4u; }
 __host__ __device__ static inline uint32_t hvs_ceil_div(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+// #{u in [0,t) : u % r != 0}
+__host__ __device__ static inline uint32_t hvs_gr(uint32_t t, uint32_t r) { return t - hvs_ceil_div(t, r); }
 
 // storage run [lo,hi) (absolute storage indices) of level j inside block range [blo,bhi)
 __host__ __device__ static inline void hvs_level_run(const HvsLevels& L, uint32_t j, uint32_t blo, uint32_t bhi,
@@ -100,14 +106,14 @@ __host__ __device__ static inline void hvs_level_run(const HvsLevels& L, uint32_
         lo = hi = 0;
         return;
     }
-    const uint32_t s = 1u << (2u * (L.K - j));
+    const uint32_t s = L.stride[j];
     const uint32_t tlo = hvs_ceil_div(blo, s), thi = hvs_ceil_div(bhi, s);
     if (j == 0) {
         lo = L.off[0] + tlo;
         hi = L.off[0] + thi;
     } else {
-        lo = L.off[j] + hvs_g4(tlo);
-        hi = L.off[j] + hvs_g4(thi);
+        lo = L.off[j] + hvs_gr(tlo, L.radix[j]);
+        hi = L.off[j] + hvs_gr(thi, L.radix[j]);
     }
 }
 
@@ -117,13 +123,47 @@ __host__ __device__ static inline uint32_t hvs_storage_to_block(const HvsLevels&
     uint32_t j = 0;
     while (j < L.K && idx >= L.off[j + 1]) ++j;
     const uint32_t i = idx - L.off[j];
-    const uint32_t s = 1u << (2u * (L.K - j));
-    if (j == 0) return i * s;
-    return (i + i / 3u + 1u) * s;  // the i-th positive integer that is not a multiple of 4
+    if (j == 0) return i * L.stride[0];
+    return (i + i / (L.radix[j] - 1u) + 1u) * L.stride[j];  // the i-th positive integer that is not a multiple of radix
 }
 
+// level table of an ordering with n rows (host)
+static inline HvsLevels hvs_make_levels(uint32_t n)
+{
+    HvsLevels L{};
+    L.nblk = (n + 31u) / 32u;
+    // radices from the last level backwards: 2, 2, 2, then 4s, while level 0 keeps >= 16 blocks (512 rows)
+    uint32_t rad[16];
+    uint32_t K = 0, S = 1;
+    for (;;) {
+        const uint32_t r = K < 3u ? 2u : 4u;
+        if (K >= 14u || L.nblk / (S * r) < 16u) break;
+        rad[K++] = r;
+        S *= r;
+    }
+    L.K = K;
+    L.stride[K] = 1;
+    L.radix[0] = 1;
+    for (uint32_t j = K; j >= 1; --j) {
+        L.radix[j] = rad[K - j];
+        L.stride[j - 1] = L.stride[j] * L.radix[j];
+    }
+    uint32_t off = 0;
+    for (uint32_t j = 0; j <= K; ++j) {
+        L.off[j] = off;
+        const uint32_t t = hvs_ceil_div(L.nblk, L.stride[j]);
+        off += (j == 0) ? t : hvs_gr(t, L.radix[j]);
+    }
+    for (uint32_t j = K + 1; j < 16u; ++j) {
+        L.off[j] = off;
+        L.stride[j] = 1;
+        L.radix[j] = 2;
+    }
+    return L;
+}
 // ---------------------------------------------------------------------------------------------
 // Index build
+
 // ---------------------------------------------------------------------------------------------
 __global__ void hvs_k_attr_keys(const float* __restrict__ D, uint32_t n, uint64_t* __restrict__ keys_ct,
                                 uint64_t* __restrict__ keys_t, uint32_t* __restrict__ ids)
@@ -253,17 +293,54 @@ __device__ __forceinline__ uint32_t hvs_type_rank(uint32_t type)
     return type == 0u ? 0u : type == 1u ? 1u : type == 3u ? 2u : type == 2u ? 4u : 3u;
 }
 
-// sort key of a query inside a batch: rank:3 | key(v):32 | key(l) >> 3
-__global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint64_t* __restrict__ keys,
-                                  uint32_t* __restrict__ idx)
+__device__ __forceinline__ uint32_t hvs_lower_bound64(const uint64_t* __restrict__ a, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;  // first index with a[i] >= key
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// position range [a,b) of a query's predicate in its ordering ((C,T) for types 0,1,3; T for type 2)
+__device__ __forceinline__ void hvs_query_range(const HvsQParams& p, const uint64_t* __restrict__ keys_ct,
+                                                const uint64_t* __restrict__ keys_t, uint32_t n, uint32_t& a, uint32_t& b)
+{
+    a = 0;
+    b = 0;
+    const uint32_t kv = hvs_attr_key(p.vf), kl = hvs_attr_key(p.l), kr = hvs_attr_key(p.r);
+    const bool lr_ok = (p.l == p.l) && (p.r == p.r);  // NaN bounds match nothing
+    if (p.type == 0u) {
+        b = n;
+    } else if (p.type == 1u) {
+        a = hvs_lower_bound64(keys_ct, n, (uint64_t)kv << 32);
+        b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv + 1ull) << 32);  // rows with T = NaN still match C==v
+    } else if (p.type == 3u && lr_ok && kl <= kr) {
+        a = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | kl);
+        b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | ((uint64_t)kr + 1ull));
+    } else if (p.type == 2u && lr_ok && kl <= kr) {
+        a = hvs_lower_bound64(keys_t, n, (uint64_t)kl << 32);
+        b = hvs_lower_bound64(keys_t, n, ((uint64_t)kr + 1ull) << 32);
+    }
+    if (b < a) b = a;
+}
+
+// sort key of a query inside a batch: rank:3 | bin of the range start:12 | range end:32.
+// Queries that share a wave (128 consecutive slots) then have nearly the same position range, so
+// the union range the wave has to stream is close to each query's own range.
+__global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
+                                  const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
+                                  uint32_t nbins, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
     const uint32_t rk = hvs_type_rank(p.type);
-    const uint32_t vk = (p.type == 1u || p.type == 3u) ? hvs_attr_key(p.vf) : 0u;
-    const uint32_t lk = (p.type == 2u || p.type == 3u) ? hvs_attr_key(p.l) : 0u;
-    keys[i] = ((uint64_t)rk << 61) | ((uint64_t)vk << 29) | (uint64_t)(lk >> 3);
+    uint32_t a, b;
+    hvs_query_range(p, keys_ct, keys_t, n, a, b);
+    const uint32_t abin = (uint32_t)(((uint64_t)a * nbins) / ((uint64_t)n + 1ull));
+    keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
     idx[i] = q0 + i;
 }
 
@@ -311,16 +388,6 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
     }
 }
 
-__device__ __forceinline__ uint32_t hvs_lower_bound64(const uint64_t* __restrict__ a, uint32_t n, uint64_t key)
-{
-    uint32_t lo = 0, hi = n;  // first index with a[i] >= key
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // per slot: position range of the predicate, norms, bound inputs; resets the top-k state
 __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
                                  const uint64_t* __restrict__ keys_t, uint32_t n,
@@ -334,22 +401,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     if (qi != 0xFFFFFFFFu) {
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
         const HvsQParams p = hvs_parse_query(q);
-        const uint32_t kv = hvs_attr_key(p.vf), kl = hvs_attr_key(p.l), kr = hvs_attr_key(p.r);
-        const bool lr_ok = (p.l == p.l) && (p.r == p.r);  // NaN bounds match nothing
-        if (p.type == 0u) {
-            a = 0;
-            b = n;
-        } else if (p.type == 1u) {
-            a = hvs_lower_bound64(keys_ct, n, (uint64_t)kv << 32);
-            b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv + 1ull) << 32);  // rows with T = NaN still match C==v
-        } else if (p.type == 3u && lr_ok && kl <= kr) {
-            a = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | kl);
-            b = hvs_lower_bound64(keys_ct, n, ((uint64_t)kv << 32) | ((uint64_t)kr + 1ull));
-        } else if (p.type == 2u && lr_ok && kl <= kr) {
-            a = hvs_lower_bound64(keys_t, n, (uint64_t)kl << 32);
-            b = hvs_lower_bound64(keys_t, n, ((uint64_t)kr + 1ull) << 32);
-        }
-        if (b < a) b = a;
+        hvs_query_range(p, keys_ct, keys_t, n, a, b);
         for (int k = 0; k < HVS_NDIM; ++k) {
             const float x = q[4 + k];
             const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
@@ -542,8 +594,8 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
                                                             uint32_t level, HvsBatch B,
                                                             unsigned long long* __restrict__ counters)
 {
-    __shared__ uint4 stile[2][HVS_TILE_U4];  // double-buffered A tile shared by the 4 waves (2 x 7 KiB)
-    __shared__ uint64_t sbuf[4][256];        // wave-private survivor buffers
+    __shared__ uint4 stile[2][HVS_STAGE * HVS_TILE_U4];  // two stages of 4 A tiles shared by the 4 waves (2 x 28 KiB)
+    __shared__ uint64_t sbuf[4][256];                    // wave-private survivor buffers
     __shared__ uint32_t srange[4][2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
@@ -615,81 +667,103 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
         wcnt = 0;
     };
 
-    // stage tile I0, then: prefetch tile i+1 into registers, multiply tile i out of LDS, store the
-    // prefetched tile into the other LDS buffer, one barrier per tile.
-    const uint32_t t = threadIdx.x;
-    const bool second = t + 256u < HVS_TILE_U4;
-    uint4 v0 = tiles[(size_t)I0 * HVS_TILE_U4 + t];
-    uint4 v1 = second ? tiles[(size_t)I0 * HVS_TILE_U4 + t + 256u] : make_uint4(0, 0, 0, 0);
-    stile[0][t] = v0;
-    if (second) stile[0][t + 256u] = v1;
-    __syncthreads();
-    for (uint32_t i = I0; i < I1; ++i) {
-        const uint32_t cur = (i - I0) & 1u;
-        const bool more = i + 1u < I1;
-        if (more) {
-            v0 = tiles[(size_t)(i + 1u) * HVS_TILE_U4 + t];
-            if (second) v1 = tiles[(size_t)(i + 1u) * HVS_TILE_U4 + t + 256u];
+    // Tiles reach LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs): a
+    // stage = 4 tiles = 28 chunks, 7 per wave.  Stage s+1 is in flight while stage s is multiplied;
+    // s_waitcnt vmcnt(0) + barrier at the end of a stage both lands the next stage (every wave has
+    // waited for its own chunks before any wave passes the barrier) and frees the current buffer
+    // (every wave has finished its ds_reads of it).  One barrier per 4 tiles keeps the waves loosely coupled: a
+    // wave that spends time on survivors of one tile catches up inside the stage.
+    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
+#pragma unroll
+        for (int k = 0; k < HVS_KSTEPS; ++k) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + 4u * (uint32_t)k;  // chunk of the stage, 0..27
+            uint32_t tile = first_tile + c / HVS_KSTEPS;
+            if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
+            const uint4* src = tiles + (size_t)tile * HVS_TILE_U4 + (c % HVS_KSTEPS) * 64u + lane;
+            const uint4* dst = &stile[buf][(c / HVS_KSTEPS) * HVS_TILE_U4 + (c % HVS_KSTEPS) * 64u];
+            // LDS byte address of the chunk (wave-uniform) goes to M0; the instruction adds lane*16.
+            // Issued as inline asm on purpose: hipcc orders every later ds_read behind a
+            // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise the prefetch
+            // with the multiply; here the only wait is the explicit one before the stage barrier.
+            const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)dst);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(lds_addr)
+                         : "memory");
         }
-        if (active && i >= i0 && i < i1) {  // wave-uniform
-            const uint32_t bp = bpos[i];
-            ++nblocks;
-            hvs_bf16x8 af[HVS_KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(stile[cur][ks * 64 + lane]);
-            // four independent accumulation chains, then four epilogues: one scheduling region, so the
-            // v_max3 trees of one query block overlap the MFMAs of the next
-            hvs_f32x16 acc[HVS_QB];
-            bool hit[HVS_QB];
-#pragma unroll
-            for (int qb = 0; qb < HVS_QB; ++qb) {
-                acc[qb] = hvs_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < HVS_KSTEPS; ++ks)
-                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc[qb], 0, 0, 0);
-            }
-            bool anyhit = false;
-#pragma unroll
-            for (int qb = 0; qb < HVS_QB; ++qb) {
-                float m = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), acc[qb][2]);
-#pragma unroll
-                for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[qb][r]), acc[qb][r + 1]);
-                m = fmaxf(m, acc[qb][15]);
-                hit[qb] = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
-#ifdef HVS_EXPERIMENT_NOHIT
-                hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
-#endif
-                anyhit = anyhit || hit[qb];
-            }
-            if (__ballot(anyhit) != 0ull) {
-#pragma unroll
+    };
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA chunks have landed
+        __syncthreads();
+    };
+    const uint32_t nstage = hvs_ceil_div(I1 - I0, HVS_STAGE);
+    issue_stage(0u, I0);
+    stage_barrier();
+    for (uint32_t st = 0; st < nstage; ++st) {
+        const uint32_t cur = st & 1u;
+        if (st + 1u < nstage) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#pragma unroll 1
+        for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
+            const uint32_t i = I0 + st * HVS_STAGE + tt;
+            if (i >= I1) break;
+            if (active && i >= i0 && i < i1) {  // wave-uniform
+                const uint32_t bp = bpos[i];
+                ++nblocks;
+                hvs_bf16x8 af[HVS_KSTEPS];
+    #pragma unroll
+                for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(stile[cur][tt * HVS_TILE_U4 + ks * 64 + lane]);
+                // four independent accumulation chains, then four epilogues: one scheduling region, so the
+                // v_max3 trees of one query block overlap the MFMAs of the next
+                hvs_f32x16 acc[HVS_QB];
+                bool hit[HVS_QB];
+    #pragma unroll
                 for (int qb = 0; qb < HVS_QB; ++qb) {
-                    if (__ballot(hit[qb]) == 0ull) continue;
-                    const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
-                        // and the append only run for the rare accumulator that beats the threshold
-                        const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
-                        if (m0 != 0ull) {
-                            const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                            const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
-                            const uint64_t mask = __ballot(c);
-                            if (mask != 0ull) {
-                                if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
-                                wcnt += (uint32_t)__popcll(mask);
-                                if (wcnt > 192u) flush();
+                    acc[qb] = hvs_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    #pragma unroll
+                    for (int ks = 0; ks < HVS_KSTEPS; ++ks)
+                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc[qb], 0, 0, 0);
+                }
+                bool anyhit = false;
+    #pragma unroll
+                for (int qb = 0; qb < HVS_QB; ++qb) {
+                    float m = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), acc[qb][2]);
+    #pragma unroll
+                    for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[qb][r]), acc[qb][r + 1]);
+                    m = fmaxf(m, acc[qb][15]);
+                    hit[qb] = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
+    #ifdef HVS_EXPERIMENT_NOHIT
+                    hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
+    #endif
+                    anyhit = anyhit || hit[qb];
+                }
+                if (__ballot(anyhit) != 0ull) {
+    #pragma unroll
+                    for (int qb = 0; qb < HVS_QB; ++qb) {
+                        if (__ballot(hit[qb]) == 0ull) continue;
+                        const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
+                            // and the append only run for the rare accumulator that beats the threshold
+                            const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
+                            if (m0 != 0ull) {
+                                const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+                                const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
+                                const uint64_t mask = __ballot(c);
+                                if (mask != 0ull) {
+                                    if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
+                                    wcnt += (uint32_t)__popcll(mask);
+                                    if (wcnt > 192u) flush();
+                                }
                             }
                         }
                     }
                 }
             }
         }
-        if (more) {
-            stile[cur ^ 1u][t] = v0;
-            if (second) stile[cur ^ 1u][t + 256u] = v1;
-        }
-        __syncthreads();
+        stage_barrier();
     }
     if (active) {
         flush();

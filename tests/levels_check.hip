@@ -1,0 +1,44 @@
+// Host-only check of the level-interleaved block order (csrc/hvs_filter.h): every block is stored
+// exactly once, and for any block range the per-level storage runs cover exactly that range.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../project---hybrid-vector-search-queries_amd/csrc/hvs_filter.h"
+
+int main()
+{
+    const uint32_t sizes[] = {100, 2047, 2048 * 32, 10000, 70000, 300001, 1000000, 10000000, 33554432};
+    for (uint32_t n : sizes) {
+        const HvsLevels L = hvs_make_levels(n);
+        if (L.off[L.K + 1] != L.nblk) { std::printf("FAIL n=%u: levels cover %u of %u blocks\n", n, L.off[L.K + 1], L.nblk); return 1; }
+        std::vector<uint32_t> where(L.nblk, 0xFFFFFFFFu);
+        for (uint32_t idx = 0; idx < L.nblk; ++idx) {
+            const uint32_t b = hvs_storage_to_block(L, idx);
+            if (b >= L.nblk || where[b] != 0xFFFFFFFFu) { std::printf("FAIL n=%u: storage %u -> block %u\n", n, idx, b); return 1; }
+            where[b] = idx;
+        }
+        srand(n);
+        for (int trial = 0; trial < 200; ++trial) {
+            uint32_t blo = (uint32_t)rand() % L.nblk, bhi = (uint32_t)rand() % (L.nblk + 1);
+            if (trial == 0) { blo = 0; bhi = L.nblk; }
+            if (blo > bhi) { uint32_t t = blo; blo = bhi; bhi = t; }
+            uint64_t covered = 0;
+            for (uint32_t j = 0; j <= L.K; ++j) {
+                uint32_t lo, hi;
+                hvs_level_run(L, j, blo, bhi, lo, hi);
+                if (lo > hi || (lo < hi && (lo < L.off[j] || hi > L.off[j + 1]))) { std::printf("FAIL n=%u level %u run [%u,%u)\n", n, j, lo, hi); return 1; }
+                for (uint32_t i = lo; i < hi; ++i) {
+                    const uint32_t b = hvs_storage_to_block(L, i);
+                    if (b < blo || b >= bhi) { std::printf("FAIL n=%u: level %u run leaves [%u,%u): block %u\n", n, j, blo, bhi, b); return 1; }
+                }
+                covered += hi - lo;
+            }
+            if (covered != (uint64_t)(bhi - blo)) { std::printf("FAIL n=%u: [%u,%u) covered %llu\n", n, blo, bhi, (unsigned long long)covered); return 1; }
+        }
+        std::printf("n=%u nblk=%u K=%u level0=%u blocks radices:", n, L.nblk, L.K, L.off[1] - L.off[0]);
+        for (uint32_t j = 1; j <= L.K; ++j) std::printf(" %u", L.radix[j]);
+        std::printf("\n");
+    }
+    std::printf("OK\n");
+    return 0;
+}

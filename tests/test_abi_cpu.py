@@ -78,3 +78,13 @@ def test_io_mirror_roundtrip(tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert PKG.calc_dist(nodes[3], np.concatenate([[0, 0], queries[0, 4:]]).astype(np.float32)) == \
         T.oracle_dist(nodes[3, 2:], queries[0, 4:], "scalar")
+
+
+def test_level_interleaved_order_is_a_partition(tmp_path):
+    """Host-only check of the index's block order (csrc/hvs_filter.h): compiled with hipcc, runs on the CPU."""
+    import subprocess
+    exe = str(tmp_path / "levels_check.out")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-w",
+                    os.path.join(T.REPO, "tests", "levels_check.hip"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
