@@ -83,7 +83,7 @@ struct hvs_ctx {
 namespace {
 
 constexpr uint32_t kBatch = 65536;        // queries answered per pass over D (exact engine)
-constexpr uint32_t kBatchMfma = 131072;   // queries per batch of the MFMA engine
+constexpr uint32_t kBatchMfma = 262144;   // queries per batch of the MFMA engine
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 
 int fail(hvs_ctx* c, int code, const std::string& msg)
@@ -318,7 +318,7 @@ int build_index(hvs_ctx* c)
 // ---------------------------------------------------------------------------------------------
 int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
 {
-    const uint32_t slots = hvs_ceil_div(nqb + 5u * 32u + 5u * HVS_GROUP, HVS_GROUP) * HVS_GROUP;
+    const uint32_t slots = hvs_ceil_div(nqb + 5u * 32u + (HVS_WG_WAVES + 1u) * HVS_GROUP, HVS_GROUP) * HVS_GROUP;
     HvsBatch& B = c->fb;
     if (slots > c->fb_slots_cap) {
         int rc;
@@ -391,7 +391,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
         const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
         HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
         if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
-        hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(B.ngroups, 4u), hvs_ceil_div(count, HVS_SEG)), dim3(256),
+        hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG)), dim3(64 * HVS_WG_WAVES),
                            0, c->stream, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t, L, level, B,
                            c->d_counters);
         if (ev >= 0) {

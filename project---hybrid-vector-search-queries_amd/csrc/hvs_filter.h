@@ -17,8 +17,9 @@
 //     fragments (K padded 100 -> 112; k = 100..102 hold -|d|^2/2 split into three BF16 pieces so
 //     that one MFMA chain yields  s = q.d - |d|^2/2  directly).
 //   * blocks are stored LEVEL-INTERLEAVED: level 0 = every S0-th block, level j = the multiples of
-//     stride[j] not in an earlier level (stride[j-1] = radix[j] * stride[j]; radix 4 for the early
-//     levels, 2 for the last three, which hold 1/8, 1/4 and 1/2 of the blocks).  Any position
+//     stride[j] not in an earlier level (stride[j-1] = radix[j] * stride[j]; radix 2 by default, so
+//     the levels hold ..., 1/8, 1/4 and 1/2 of the blocks; HVS_RADIX2_LEVELS selects radix 4 for
+//     the early levels).  Any position
 //     range meets every level in one contiguous storage run, and level j multiplies the rows a
 //     query has seen by radix[j].  A query's threshold tau therefore tightens geometrically and
 //     each round hands only ~100 (radix-1) (+ error band) candidates per query to the exact
@@ -34,12 +35,25 @@
 #define HVS_KPAD 112          // padded contraction length (7 MFMA k-steps of 16)
 #define HVS_KSTEPS 7
 #define HVS_TILE_U4 (HVS_KSTEPS * 64)  // uint4 per 32-row tile (7 KiB)
+#ifndef HVS_QB
 #define HVS_QB 4              // query blocks (of 32) per wave in the filter kernel
+#endif
 #define HVS_GROUP (32 * HVS_QB)
 #define HVS_FCAP 1024         // per-query candidate keys per round
 #define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
 #define HVS_SEG 128           // row blocks per filter work item
+#ifndef HVS_STAGE
 #define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage)
+#endif
+#ifndef HVS_RADIX2_LEVELS
+#define HVS_RADIX2_LEVELS 14u  // how many of the last levels double (rather than quadruple) the rows seen (all)
+#endif
+#ifndef HVS_WG_WAVES
+#define HVS_WG_WAVES 4        // waves (= query groups) per filter workgroup sharing one tile stream
+#endif
+#ifndef HVS_FILTER_OCC
+#define HVS_FILTER_OCC 2      // waves per SIMD the filter kernel is compiled for
+#endif
 #define HVS_TOPCAP 128        // stored top list stride
 
 typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
@@ -136,7 +150,7 @@ static inline HvsLevels hvs_make_levels(uint32_t n)
     uint32_t rad[16];
     uint32_t K = 0, S = 1;
     for (;;) {
-        const uint32_t r = K < 3u ? 2u : 4u;
+        const uint32_t r = K < HVS_RADIX2_LEVELS ? 2u : 4u;
         if (K >= 14u || L.nblk / (S * r) < 16u) break;
         rad[K++] = r;
         S *= r;
@@ -366,7 +380,7 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
     if (threadIdx.x == 0u) {
         uint32_t s = 0;
         for (uint32_t rk = 0; rk < 5u; ++rk) {
-            if (rk == 4u) s = hvs_ceil_div(s, 4u * HVS_GROUP) * (4u * HVS_GROUP);  // T-ordering part starts a new QUAD of groups
+            if (rk == 4u) s = hvs_ceil_div(s, HVS_WG_WAVES * HVS_GROUP) * (HVS_WG_WAVES * HVS_GROUP);  // T-ordering part starts a new filter workgroup
             slot0[rk] = s;
             const uint32_t cnt = first[rk + 1] - first[rk];
             s += hvs_ceil_div(cnt, 32u) * 32u;
@@ -587,7 +601,7 @@ __device__ __forceinline__ hvs_bf16x8 hvs_as_bf16x8(const uint4& u)
     return c.b8;
 }
 
-__global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restrict__ tiles_ct,
+__global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_mfma(const uint4* __restrict__ tiles_ct,
                                                             const uint4* __restrict__ tiles_t,
                                                             const uint32_t* __restrict__ bpos_ct,
                                                             const uint32_t* __restrict__ bpos_t, HvsLevels L,
@@ -595,8 +609,8 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
                                                             unsigned long long* __restrict__ counters)
 {
     __shared__ uint4 stile[2][HVS_STAGE * HVS_TILE_U4];  // two stages of 4 A tiles shared by the 4 waves (2 x 28 KiB)
-    __shared__ uint64_t sbuf[4][256];                    // wave-private survivor buffers
-    __shared__ uint32_t srange[4][2];
+    __shared__ uint64_t sbuf[HVS_WG_WAVES][256];         // wave-private survivor buffers
+    __shared__ uint32_t srange[HVS_WG_WAVES][2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
     // grid: x = quad of groups (fastest), y = ABSOLUTE storage segment of the level.  Consecutive
@@ -605,12 +619,13 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
     // The quad's 4 waves walk the segment together: every tile is fetched once per workgroup
     // into LDS and read from there by all 4 waves (ds_read_b128).  All groups of a quad use the
     // same ordering (the T-ordering part of a batch starts at a quad boundary).
-    const uint32_t g = blockIdx.x * 4u + wv;
-    const uint32_t gq = blockIdx.x * 4u;  // first group of the quad decides the ordering
+    const uint32_t g = blockIdx.x * HVS_WG_WAVES + wv;
+    const uint32_t gq = blockIdx.x * HVS_WG_WAVES;  // first group of the workgroup decides the ordering
     const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
-    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
+    const uint32_t lvl_off = L.off[level], lvl_stride = L.stride[level], lvl_radix = L.radix[level];
+    const uint32_t seg_lo = lvl_off + blockIdx.y * HVS_SEG;
     uint32_t i0 = 0, i1 = 0;  // this wave's tiles [i0,i1) inside the segment (empty when i0 >= i1)
     if (g < B.ngroups && B.gord[g] == ord) {
         uint32_t lo, hi;
@@ -627,11 +642,13 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
     __syncthreads();
     uint32_t I0 = srange[0][0], I1 = srange[0][1];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < HVS_WG_WAVES; ++w) {
         I0 = srange[w][0] < I0 ? srange[w][0] : I0;
         I1 = srange[w][1] > I1 ? srange[w][1] : I1;
     }
     if (I0 >= I1) return;  // uniform over the workgroup
+    i0 = __builtin_amdgcn_readfirstlane(i0);  // wave-uniform by construction: keep the tile test scalar
+    i1 = __builtin_amdgcn_readfirstlane(i1);
     const bool active = i0 < i1;
 
     // resident query operands
@@ -675,8 +692,9 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
     // wave that spends time on survivors of one tile catches up inside the stage.
     auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
 #pragma unroll
-        for (int k = 0; k < HVS_KSTEPS; ++k) {
-            const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + 4u * (uint32_t)k;  // chunk of the stage, 0..27
+        for (int k = 0; k < (HVS_STAGE * HVS_KSTEPS + HVS_WG_WAVES - 1) / HVS_WG_WAVES; ++k) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + (uint32_t)HVS_WG_WAVES * (uint32_t)k;  // chunk of the stage
+            if (c >= HVS_STAGE * HVS_KSTEPS) break;
             uint32_t tile = first_tile + c / HVS_KSTEPS;
             if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
             const uint4* src = tiles + (size_t)tile * HVS_TILE_U4 + (c % HVS_KSTEPS) * 64u + lane;
@@ -695,15 +713,19 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
         }
     };
     auto stage_barrier = [&]() {
+#ifndef HVS_EXPERIMENT_NOSYNC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA chunks have landed
         __syncthreads();
+#endif
     };
     const uint32_t nstage = hvs_ceil_div(I1 - I0, HVS_STAGE);
     issue_stage(0u, I0);
     stage_barrier();
     for (uint32_t st = 0; st < nstage; ++st) {
         const uint32_t cur = st & 1u;
+#ifndef HVS_EXPERIMENT_NODMA
         if (st + 1u < nstage) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#endif
 #pragma unroll 1
         for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
             const uint32_t i = I0 + st * HVS_STAGE + tt;
@@ -732,11 +754,12 @@ __global__ __launch_bounds__(256, 2) void hvs_k_filter_mfma(const uint4* __restr
     #pragma unroll
                     for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[qb][r]), acc[qb][r + 1]);
                     m = fmaxf(m, acc[qb][15]);
-                    hit[qb] = m >= theta[qb] && bp * 32u + 32u > ra[qb] && bp * 32u < rb[qb];
+                    // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
+                hit[qb] = (m >= theta[qb]) & (bp * 32u + 32u > ra[qb]) & (bp * 32u < rb[qb]);
     #ifdef HVS_EXPERIMENT_NOHIT
                     hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
     #endif
-                    anyhit = anyhit || hit[qb];
+                    anyhit = anyhit | hit[qb];
                 }
                 if (__ballot(anyhit) != 0ull) {
     #pragma unroll

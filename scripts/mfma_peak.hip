@@ -2,6 +2,7 @@
 // (4 interleaved chains of 7, 2 waves per SIMD), with and without the v_max3 epilogue.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void k(const uint4* __restrict__ in, float*
     out[blockIdx.x * 256 + threadIdx.x] = keep;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     uint4* in; float* out;
     std::vector<unsigned> h(35 * 64 * 4);
@@ -49,7 +50,7 @@ int main()
     hipMalloc(&in, h.size() * 4); hipMalloc(&out, 2048 * 256 * 4);
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int iters = 4000, blocks = 512;  // 2 workgroups per CU
+    const int iters = (argc > 1 ? atoi(argv[1]) : 4000), blocks = 512;  // 2 workgroups per CU
     for (int epi = 0; epi < 2; ++epi) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(a);
