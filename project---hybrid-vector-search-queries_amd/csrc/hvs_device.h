@@ -167,6 +167,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
     }
     uint64_t prefix = 0;
     uint32_t r = KEEP;
+    uint32_t rem = cnt;  // keys that still match the decided prefix bits
     for (int bit = 63; bit >= 0; --bit) {
         const uint64_t himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
         uint32_t c0 = 0;
@@ -177,7 +178,26 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         }
         if (r > c0) {
             r -= c0;
+            rem -= c0;
             prefix |= (1ull << bit);
+        } else {
+            rem = c0;
+        }
+        if (rem == 1u) {
+            // one key left under this prefix: it is the answer (keys are distinct), no need to walk
+            // the remaining bits (distances usually separate within the first ~25 bits)
+            const uint64_t lomask = ~0ull << bit;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t mm = __ballot(valid[i] && (((k[i] ^ prefix) & lomask) == 0ull));
+                if (mm != 0ull) {
+                    const int src = (int)__builtin_ctzll(mm);
+                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)k[i], src);
+                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(k[i] >> 32), src);
+                    prefix = ((uint64_t)hi << 32) | lo;
+                }
+            }
+            break;
         }
     }
     uint32_t base = 0;

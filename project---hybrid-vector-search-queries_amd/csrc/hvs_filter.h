@@ -798,24 +798,41 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // hvs_k_rescore -- exact-order distances of the filter's survivors: one lane per (slot,pos) pair,
 // the same arithmetic as everywhere else (hvs_exact_dist), key appended to the slot's list.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hvs_k_rescore(const float* __restrict__ D, const float* __restrict__ Q, HvsBatch B,
+__global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, const float* __restrict__ Q, HvsBatch B,
                                                      const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
                                                      unsigned long long* __restrict__ counters)
 {
+    // the group's 128 query vectors are staged in LDS once per block (51 KB): a lane then reads its
+    // pair's query with ds_read_b128 and only the data row is gathered from global memory
+    __shared__ float sq[HVS_GROUP][HVS_NDIM];
     const uint32_t g = blockIdx.y;
     uint32_t np = B.paircnt[g];
     // a group whose pair list overflowed holds unwritten entries past the failed flush: none of
     // its pairs are used, all of its queries are re-run by the exact engine
     if (np > HVS_GCAP || B.goverflow[g]) np = 0;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        atomicAdd(&counters[2], (unsigned long long)np);
+        if (B.goverflow[g]) {
+            for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
+        }
+    }
+    if (blockIdx.x * blockDim.x >= np) return;  // uniform over the block
+    for (uint32_t e = threadIdx.x; e < HVS_GROUP * (HVS_NDIM / 4); e += blockDim.x) {
+        const uint32_t ql = e / (HVS_NDIM / 4), c4 = e % (HVS_NDIM / 4);
+        const uint32_t qi = B.qid[g * HVS_GROUP + ql];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi != 0xFFFFFFFFu) v = *reinterpret_cast<const float4*>(Q + (size_t)qi * HVS_QCOLS + 4 + 4 * c4);
+        *reinterpret_cast<float4*>(&sq[ql][4 * c4]) = v;
+    }
+    __syncthreads();
     const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
         const uint64_t pr = B.pairs[(size_t)g * HVS_GCAP + e];
         const uint32_t slot = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
         const uint32_t id = perm[pos];
-        const uint32_t qi = B.qid[slot];
         const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
-        const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
+        const float* qv = &sq[slot - g * HVS_GROUP][0];
         const float dist = hvs_exact_dist(dv, qv);
         if (dist <= B.tau[slot]) {
             const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
@@ -823,12 +840,6 @@ __global__ __launch_bounds__(256) void hvs_k_rescore(const float* __restrict__ D
                 B.cand[(size_t)slot * HVS_FCAP + k] = hvs_make_key(dist, id);
             else
                 B.overflow[slot] = 1u;
-        }
-    }
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        atomicAdd(&counters[2], (unsigned long long)np);
-        if (B.goverflow[g]) {
-            for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
         }
     }
 }
@@ -858,10 +869,11 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     const uint32_t qi = B.qid[slot];
     if (qi == 0xFFFFFFFFu) return;
     uint64_t* buf = sbuf[w];
-    uint32_t cnt = B.topcnt[slot];
-    for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * HVS_TOPCAP + e];
     uint32_t m = B.candcnt[slot];
     if (m > HVS_FCAP) m = HVS_FCAP;
+    if (m == 0u && !final) return;  // nothing new at this level: top-100, tau and theta stand
+    uint32_t cnt = B.topcnt[slot];
+    for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * HVS_TOPCAP + e];
     const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
     for (uint32_t off = 0; off < m; off += 64u) {
         if (cnt + 64u > 256u) {
