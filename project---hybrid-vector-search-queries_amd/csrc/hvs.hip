@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -82,8 +83,16 @@ struct hvs_ctx {
 
 namespace {
 
-constexpr uint32_t kBatch = 65536;        // queries answered per pass over D (exact engine)
-constexpr uint32_t kBatchMfma = 262144;   // queries per batch of the MFMA engine
+uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    const unsigned long x = std::strtoul(v, nullptr, 10);
+    return x < lo ? lo : (x > hi ? hi : (uint32_t)x);
+}
+// queries answered per pass over D; HVS_EXACT_BATCH / HVS_MFMA_BATCH override (tests use small batches)
+const uint32_t kBatch = env_u32("HVS_EXACT_BATCH", 65536u, 64u, 1u << 20);
+const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 262144u, 128u, 1u << 20);
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 
 int fail(hvs_ctx* c, int code, const std::string& msg)
@@ -309,6 +318,15 @@ int build_index(hvs_ctx* c)
                        c->d_bpos_t, c->d_bounds);
     HVS_HIP(c, hipGetLastError());
     HVS_HIP(c, hipStreamSynchronize(c->stream));
+    // the error bound needs finite row norms: data with inf/NaN components (or |d|^2 overflowing f32)
+    // is answered by the exact engine only
+    HvsBounds hb{};
+    HVS_HIP(c, hipMemcpy(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost));
+    if (!(std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho)) ||
+        hb.hmax > 1.0e30f) {
+        free_index(c);
+        return HVS_OK;
+    }
     c->have_index = true;
     return HVS_OK;
 }

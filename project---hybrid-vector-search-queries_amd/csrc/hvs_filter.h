@@ -433,7 +433,8 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     B.nqb[s] = hvs_round_up_f32(sqrt(nb2) + 1e-30);
     B.topcnt[s] = 0;
     B.candcnt[s] = 0;
-    B.overflow[s] = 0;
+    // a query with non-finite components has no usable bound: it is answered by the exact engine
+    B.overflow[s] = (qi != 0xFFFFFFFFu && !(qn < 1.0e30)) ? 1u : 0u;
     B.tau[s] = __builtin_inff();
     // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
     B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();

@@ -11,24 +11,30 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TILE_U4 448
+#ifndef LAB_QB
+#define LAB_QB 4
+#endif
+#ifndef LAB_OCC
+#define LAB_OCC 2
+#endif
 #ifndef LAB_DMA_POLICY
 #define LAB_DMA_POLICY ""
 #endif
 
-__global__ __launch_bounds__(256, 2) void lab(const uint4* __restrict__ in, const uint4* __restrict__ tiles, float* __restrict__ out,
+__global__ __launch_bounds__(256, LAB_OCC) void lab(const uint4* __restrict__ in, const uint4* __restrict__ tiles, float* __restrict__ out,
                                               int ntiles, float theta_in)
 {
     __shared__ uint4 stile[2][4 * TILE_U4];
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     union { uint4 u; bf16x8 b; } c;
-    bf16x8 bq[4][7], af[7];
-    for (int q = 0; q < 4; ++q)
-        for (int s = 0; s < 7; ++s) { c.u = in[(q * 7 + s) * 64 + lane]; bq[q][s] = c.b; }
+    bf16x8 bq[LAB_QB][7], af[7];
+    for (int q = 0; q < LAB_QB; ++q)
+        for (int s = 0; s < 7; ++s) { c.u = in[((q % 4) * 7 + s) * 64 + lane]; bq[q][s] = c.b; asm volatile("" : "+v"(bq[q][s])); }
     for (int s = 0; s < 7; ++s) { c.u = in[(28 + s) * 64 + lane]; af[s] = c.b; }
     for (int e = threadIdx.x; e < 2 * 4 * TILE_U4; e += 256) (&stile[0][0])[e] = in[e % (35 * 64)];
     __syncthreads();
-    float theta[4] = {theta_in, theta_in + 1.f, theta_in + 2.f, theta_in + 3.f};
-    unsigned ra[4] = {0, 0, 0, 0}, rb[4] = {~0u, ~0u, ~0u, ~0u};
+    float theta[LAB_QB]; unsigned ra[LAB_QB], rb[LAB_QB];
+    for (int q = 0; q < LAB_QB; ++q) { theta[q] = theta_in + (float)q; ra[q] = 0; rb[q] = ~0u; }
     float keep = 0.f;
     unsigned hits = 0;
     const int nstage = ntiles / 4;
@@ -63,9 +69,9 @@ __global__ __launch_bounds__(256, 2) void lab(const uint4* __restrict__ in, cons
 #else
             asm volatile("" : "+v"(af[0]));
 #endif
-            f32x16 acc[4];
+            f32x16 acc[LAB_QB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LAB_QB; ++q) {
                 acc[q] = f32x16{0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #pragma unroll
                 for (int s = 0; s < 7; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bq[q][s], acc[q], 0, 0, 0);
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void lab(const uint4* __restrict__ in, cons
 #ifdef LAB_EPI
             bool anyhit = false;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LAB_QB; ++q) {
                 float m = fmaxf(fmaxf(acc[q][0], acc[q][1]), acc[q][2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[q][r]), acc[q][r + 1]);
@@ -113,13 +119,13 @@ int main(int argc, char** argv)
     hipMalloc(&tiles, tile_bytes); hipMemset(tiles, 0x3c, tile_bytes);
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int blocks = 2048;
+    const int blocks = LAB_OCC == 1 ? 1024 : 2048;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL(lab, dim3(blocks), dim3(256), 0, 0, in, tiles, out, ntiles, 1.0e30f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
-        const double mfma = (double)blocks * 4 * ntiles * 28;
+        const double mfma = (double)blocks * 4 * ntiles * 7 * LAB_QB;
         std::printf("%s: %.2f ms  %.0f TFLOP/s\n", LAB_NAME, ms, mfma * 32768.0 / (ms * 1e-3) / 1e12);
     }
     return 0;

@@ -212,3 +212,48 @@ def test_mfma_engine_overflow_falls_back_to_exact():
     ref, _ = T.oracle_query(nodes, queries)
     st = T.check_parity(nodes, queries, ids, ref, got_dists=dists)
     assert st["identical"] == st["queries"]
+
+
+def test_mfma_accumulation_error_is_inside_the_budget(tmp_path):
+    """the filter's bound assumes |mfma chain - exact| <= 256 u sum|terms|; measure it."""
+    import subprocess
+    exe = str(tmp_path / "mfma_bound_check.out")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w",
+                    os.path.join(T.REPO, "tests", "mfma_bound_check.hip"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_many_small_batches_and_nonfinite_inputs():
+    """HVS_MFMA_BATCH / HVS_EXACT_BATCH split one call into many batches; queries or data with inf/NaN
+    components are answered by the exact engine."""
+    import subprocess
+    import sys
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import hvs_testlib as T
+PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
+nodes = T.gen_data(40000, 31, T.GEN_V1, 10); queries = T.gen_queries(700, 32, T.GEN_V1, 10)
+queries[5, 10] = np.inf; queries[6, 50] = 1e30
+ref, _ = T.oracle_query(nodes, queries)
+for engine in (1, 2):
+    with PKG.Engine(0) as e:
+        e.set_engine(engine); e.load_data(nodes)
+        ids, d = e.query(queries, 1.0)
+        t = e.last_timing()
+    ok = [i for i in range(700) if i not in (5, 6)]
+    T.check_parity(nodes, queries[ok], ids[ok], ref[ok], got_dists=d[ok])
+    assert t.engine == engine, (t.engine, engine)
+    if engine == 2: assert t.fallback_queries >= 2
+bad = nodes.copy(); bad[123, 7] = np.inf
+with PKG.Engine(0) as e:
+    e.set_engine(2); e.load_data(bad)
+    ids, d = e.query(queries[:50], 1.0)
+    assert e.last_timing().engine == 1      # non-finite data: no index, exact engine
+print('SUBPROCESS-OK')
+"""
+    env = dict(os.environ, HVS_MFMA_BATCH="256", HVS_EXACT_BATCH="128")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=T.REPO)
+    assert "SUBPROCESS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
