@@ -257,3 +257,44 @@ print('SUBPROCESS-OK')
     env = dict(os.environ, HVS_MFMA_BATCH="256", HVS_EXACT_BATCH="128")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=T.REPO)
     assert "SUBPROCESS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_full_size_d1e7_engines_agree_and_properties_hold():
+    """BASELINE.json headline data size (D = 10^7 rows, generated in HBM).  The MFMA engine must give
+    the exact engine's bits on a few thousand mixed queries; size-independent properties are
+    checked on all of them and the oracle confirms a handful (the CPU needs ~0.1 s per query here)."""
+    n, nq = 10_000_000, 4096
+    with PKG.Engine(0) as e:
+        e.set_engine(PKG.ENGINE_MFMA_FILTER)
+        e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
+        e.gen_queries(nq, T.SEED_QUERY, T.GEN_V1, 100, -1, 0)
+        queries = e.download_queries(0, nq)
+        e.query_resident(0, nq, 1.0)
+        e.sync()
+        t = e.last_timing()
+        ids, dists = e.download_results(0, nq)
+        assert t.engine == PKG.ENGINE_MFMA_FILTER and t.fallback_queries == 0
+        # the same queries through the exact engine (first 1024: ~10^10 exact pairs)
+        e.set_engine(PKG.ENGINE_EXACT_SCAN)
+        e.query_resident(0, 1024, 1.0)
+        e.sync()
+        assert e.last_timing().engine == PKG.ENGINE_EXACT_SCAN
+        ids_x, dists_x = e.download_results(0, 1024)
+        nodes = e.download_data(0, n)
+    assert np.array_equal(ids[:1024], ids_x) and np.array_equal(dists[:1024].view(np.uint32), dists_x.view(np.uint32))
+    # properties on all 4096 answers
+    assert ids.max() < n and np.all(np.diff(dists, axis=1) >= 0)
+    assert np.array_equal(T.oracle_dists_for_ids(nodes, queries, ids).view(np.uint32), dists.view(np.uint32))
+    typ = queries[:, 0].astype(int)
+    c = nodes[:, 0][ids]
+    tt = nodes[:, 1][ids]
+    has_c, has_t = (typ & 1) == 1, (typ & 2) == 2
+    notpad = ids < n - 100                                    # padding ids come from the last 100 rows only
+    assert np.all((c == queries[:, 1:2])[has_c][notpad[has_c]])
+    assert np.all(((tt >= queries[:, 2:3]) & (tt <= queries[:, 3:4]))[has_t][notpad[has_t]])
+    for row in ids[typ == 0][::29]:
+        assert len(set(row.tolist())) == 100                  # no duplicates when >= 100 rows match
+    # the oracle on a few queries of every type
+    pick = np.concatenate([np.nonzero(typ == k)[0][:3] for k in range(4)])
+    ref, _ = T.oracle_query(nodes, queries[pick], threads=16)
+    T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
