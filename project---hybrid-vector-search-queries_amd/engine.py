@@ -68,7 +68,16 @@ def build_cli(verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=_CSRC)
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", os.path.join(_CSRC, "hvs_compare.cpp"), "-o", compare_path()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_CSRC)
     return cli_path()
+
+
+def compare_path():
+    """The reference-compatible result checker (csrc/hvs_compare.cpp, CLI of src/compare_data.cpp)."""
+    return os.path.join(_CSRC, "hvs_compare.out")
 
 
 def exported_symbols():

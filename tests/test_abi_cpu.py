@@ -88,3 +88,36 @@ def test_level_interleaved_order_is_a_partition(tmp_path):
                     os.path.join(T.REPO, "tests", "levels_check.hip"), "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+
+
+def test_compare_tool_matches_reference_cli_and_is_tie_aware(tmp_path):
+    """csrc/hvs_compare.out: the reference's compare_data.cpp verdict lines on .dist files plus the
+    tie-aware id check of SURVEY 8c.  Pure host code; the golden holds the reference engines' outputs."""
+    import subprocess
+    PKG.build_cli()
+    z = np.load(os.path.join(T.GOLDEN_DIR, "pad_2k_x200.npz"))
+    nodes = T.gen_data(int(z["n"]), int(z["seed_data"]), int(z["profile"]), int(z["ncat"]))
+    queries = T.gen_queries(int(z["nq"]), int(z["seed_query"]), int(z["profile"]), int(z["ncat"]), int(z["force_type"]))
+    T.write_bin(str(tmp_path / "d.bin"), nodes)
+    T.write_bin(str(tmp_path / "q.bin"), queries)
+    can, _ = T.oracle_query(nodes, queries)
+    names = {"opt": z["ids_optimized"], "par": z["ids_optimized_parallel"], "base": z["ids_baseline"], "can": can}
+    for k, ids in names.items():
+        PKG.SaveKNN(ids, str(tmp_path / f"{k}.bin"))
+        PKG.SaveKNNFull(nodes, queries, ids, str(tmp_path / f"{k}.bin.dist"))
+    r = subprocess.run([PKG.compare_path(), str(tmp_path / "opt.bin"), str(tmp_path / "par.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Datasets are the same!" in r.stdout
+    r = subprocess.run([PKG.compare_path(), "--strict", "--data", str(tmp_path / "d.bin"), "--queries", str(tmp_path / "q.bin"),
+                        str(tmp_path / "opt.bin"), str(tmp_path / "can.bin"), str(tmp_path / "par.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count(" 0 VIOLATIONS") == 3, r.stdout
+    # the baseline engine sums in scalar order: a different answer for a few queries (reference optimized.hpp:34-42)
+    r = subprocess.run([PKG.compare_path(), "--strict", "--data", str(tmp_path / "d.bin"), "--queries", str(tmp_path / "q.bin"),
+                        str(tmp_path / "opt.bin"), str(tmp_path / "base.bin")], capture_output=True, text=True)
+    assert "similar under error delta" in r.stdout or "Datasets are the same!" in r.stdout
+    broken = can.copy()
+    broken[3, 0] = (broken[3, 0] + 1) % int(z["n"])
+    PKG.SaveKNN(broken, str(tmp_path / "broken.bin"))
+    PKG.SaveKNNFull(nodes, queries, broken, str(tmp_path / "broken.bin.dist"))
+    r = subprocess.run([PKG.compare_path(), "--strict", "--data", str(tmp_path / "d.bin"), "--queries", str(tmp_path / "q.bin"),
+                        str(tmp_path / "can.bin"), str(tmp_path / "broken.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 VIOLATIONS" in r.stdout
