@@ -388,10 +388,18 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
     const HvsLevels L = c->lv;
     const uint32_t n = c->n;
 
-    // ~2048 queries per start-position bin: inside a bin queries are ordered by range end
-    const uint32_t nbins = std::max(1u, std::min(4096u, nqb / 2048u));
+    // ~4096 queries of a predicate class per start-position bin (32 groups); inside a bin queries are
+    // ordered by range end, so the 4 groups of a filter workgroup stream nearly the same run of tiles
+    HVS_HIP(c, hipMemsetAsync(c->d_layout + 8, 0, 8 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(hvs_k_count_classes, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
+                       c->d_layout + 8);
+    uint32_t counts[5] = {0, 0, 0, 0, 0};
+    HVS_HIP(c, hipMemcpyAsync(counts, c->d_layout + 8, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    HvsBins bins;
+    for (int k = 0; k < 5; ++k) bins.nbins[k] = std::max(1u, std::min(4096u, counts[k] / 4096u));
     hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys_ct,
-                       c->d_keys_t, n, nbins, c->d_keys, c->d_qidx);
+                       c->d_keys_t, n, bins, c->d_keys, c->d_qidx);
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                          (size_t)nqb, 0, 64, c->stream));

@@ -343,9 +343,22 @@ __device__ __forceinline__ void hvs_query_range(const HvsQParams& p, const uint6
 // sort key of a query inside a batch: rank:3 | bin of the range start:12 | range end:32.
 // Queries that share a wave (128 consecutive slots) then have nearly the same position range, so
 // the union range the wave has to stream is close to each query's own range.
+struct HvsBins {
+    uint32_t nbins[5];  // start-position bins per predicate class rank
+};
+
+// population of each predicate class in the batch (sizes the start-position bins)
+__global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint32_t* __restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
+    atomicAdd(&counts[hvs_type_rank(p.type)], 1u);
+}
+
 __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
                                   const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
-                                  uint32_t nbins, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+                                  HvsBins bins, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
@@ -353,7 +366,7 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     const uint32_t rk = hvs_type_rank(p.type);
     uint32_t a, b;
     hvs_query_range(p, keys_ct, keys_t, n, a, b);
-    const uint32_t abin = (uint32_t)(((uint64_t)a * nbins) / ((uint64_t)n + 1ull));
+    const uint32_t abin = (uint32_t)(((uint64_t)a * bins.nbins[rk]) / ((uint64_t)n + 1ull));
     keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
     idx[i] = q0 + i;
 }
