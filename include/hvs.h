@@ -64,6 +64,14 @@ const char *hvs_last_error(const hvs_ctx *ctx);
 /* Library-level message for failures that have no context (hvs_create). */
 const char *hvs_last_global_error(void);
 int hvs_set_engine(hvs_ctx *ctx, int engine);
+/* Summation order of the distances.  HVS_ORDER_SIMD (default) is the hot path's AVX2 order
+ * (optimized_impl.h:96-125) used by optimized.hpp / optimized_parallel.hpp; HVS_ORDER_SCALAR is the
+ * sequential order of the reference's baseline engine (baseline.hpp:53-64; BASELINE.json configs[0]),
+ * answered by the exact engine.  The two orders give different f32 distances and, now and then,
+ * different neighbours (reference optimized.hpp:34-42). */
+#define HVS_ORDER_SIMD 0
+#define HVS_ORDER_SCALAR 1
+int hvs_set_distance_order(hvs_ctx *ctx, int order);
 
 /* ---- data set D (replaces `nodes`, reference src/test.cpp:71-73 + io.h:111-136) ---------- */
 

@@ -32,6 +32,7 @@ struct hvs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int engine = HVS_ENGINE_AUTO;
+    bool scalar_order = false;  // baseline engine's summation order (exact engine only)
     std::string err;
 
     // data set, raw rows n x 102 (the io.h layout) resident in HBM
@@ -221,16 +222,25 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
     const int ev = (count_stats && c->n_launch_events < hvs_ctx::kMaxLaunchEvents) ? c->n_launch_events : -1;
     if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
     if (sn > 0) {
-        hipLaunchKernelGGL(hvs_k_scan_exact, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream, c->d_data,
-                           c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
-                           count_stats ? c->d_counters : c->d_counters + 4);
+        if (c->scalar_order)
+            hipLaunchKernelGGL(hvs_k_scan_exact<true>, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream,
+                               c->d_data, c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
+                               count_stats ? c->d_counters : c->d_counters + 4);
+        else
+            hipLaunchKernelGGL(hvs_k_scan_exact<false>, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream,
+                               c->d_data, c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
+                               count_stats ? c->d_counters : c->d_counters + 4);
     }
     if (ev >= 0) {
         HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
         c->n_launch_events++;
     }
-    hipLaunchKernelGGL(hvs_k_select, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                       qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+    if (c->scalar_order)
+        hipLaunchKernelGGL(hvs_k_select<true>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+    else
+        hipLaunchKernelGGL(hvs_k_select<false>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -454,7 +464,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     HVS_HIP(c, hipSetDevice(c->device));
     const uint32_t sn = sample_rows(sample_proportion, c->n);
     // the index orders ALL rows; a sampled prefix [0,sn) is answered by the exact engine
-    bool mfma = c->have_index && sn == c->n &&
+    bool mfma = c->have_index && sn == c->n && !c->scalar_order &&
                 (c->engine == HVS_ENGINE_MFMA_FILTER || (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
     c->timing_valid = false;
     c->n_launch_events = 0;
@@ -575,6 +585,14 @@ int hvs_set_engine(hvs_ctx* c, int engine)
         HVS_HIP(c, hipSetDevice(c->device));
         return build_index(c);
     }
+    return HVS_OK;
+}
+
+int hvs_set_distance_order(hvs_ctx* c, int order)
+{
+    if (!c) return HVS_EINVAL;
+    if (order != HVS_ORDER_SIMD && order != HVS_ORDER_SCALAR) return fail(c, HVS_EINVAL, "hvs_set_distance_order: unknown order");
+    c->scalar_order = order == HVS_ORDER_SCALAR;
     return HVS_OK;
 }
 

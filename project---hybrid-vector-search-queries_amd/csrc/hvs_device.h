@@ -124,6 +124,23 @@ __device__ __forceinline__ float hvs_exact_dist_pk(const DV2& d2, const QV2& q2)
     return a + b2;
 }
 
+// Sequential-order squared L2 of the reference's BASELINE engine (include/baseline.hpp:53-64,
+// compare_with_id) and of the .dist side file (include/io.h:38-48): sum = sum + diff*diff for
+// dims 0..99 in order.  A different f32 value than the SIMD order above (the reference documents
+// the discrepancy, optimized.hpp:34-42 and src/fp_inaccuracy_test.cpp).
+template <typename DV, typename QV>
+__device__ __forceinline__ float hvs_scalar_order_dist(const DV& d, const QV& q)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < HVS_NDIM; ++i) {
+        float t = d[i] - q[i];
+        t = t * t;
+        sum = sum + t;
+    }
+    return sum;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Candidate keys: (distance bits << 32) | row id.  Distances are sums of squares (>= +0), so
 // their IEEE bit patterns order like unsigned integers and ascending u64 order is exactly the

@@ -81,6 +81,18 @@ struct HvsUniformRow2 {
     __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
 };
 
+struct HvsUniformRow1 {
+    const float* __restrict__ p;
+    __device__ __forceinline__ float operator[](int i) const { return p[i]; }
+};
+struct HvsPairAsScalar {  // view the lane's 50 query pairs as 100 floats
+    const hvs_f2* q2;
+    __device__ __forceinline__ float operator[](int i) const { return (i & 1) ? q2[i >> 1].y : q2[i >> 1].x; }
+};
+
+// SCALAR_ORDER = false: the hot path's SIMD summation order (optimized_impl.h:96-125);
+// SCALAR_ORDER = true : the baseline engine's sequential order (baseline.hpp:53-64), BASELINE.json configs[0].
+template <bool SCALAR_ORDER>
 __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
@@ -126,7 +138,14 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
         nscan += 64u;
 
         HvsUniformRow2 dv{reinterpret_cast<const hvs_f2*>(row + 2)};
-        const float dist = hvs_exact_dist_pk(dv, q2);
+        float dist;
+        if (SCALAR_ORDER) {
+            HvsUniformRow1 d1{row + 2};
+            HvsPairAsScalar q1{q2};
+            dist = hvs_scalar_order_dist(d1, q1);
+        } else {
+            dist = hvs_exact_dist_pk(dv, q2);
+        }
 
         if (pass && dist < tau) {
             mylist[cnt] = hvs_make_key(dist, j);
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
 // emit ids in ascending (dist, id) order (get_knn_sorted, optimized_impl.h:392-415).
 // One wave per query, 4 queries per 256-thread block, a 256-key LDS buffer per wave.
 // ---------------------------------------------------------------------------------------------
+template <bool SCALAR_ORDER>
 __global__ __launch_bounds__(256) void hvs_k_select(
     const float* __restrict__ D, uint32_t n, const float* __restrict__ Q, const uint32_t* __restrict__ qorder,
     uint32_t nq, uint32_t nq_pad, uint32_t nchunks, const uint64_t* __restrict__ cand,
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
         if (e < HVS_KNN) {
             const uint32_t id = n - 1u - (e - cnt);
             const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
-            buf[e] = hvs_make_key(hvs_exact_dist(dv, qv), id);
+            buf[e] = hvs_make_key(SCALAR_ORDER ? hvs_scalar_order_dist(dv, qv) : hvs_exact_dist(dv, qv), id);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

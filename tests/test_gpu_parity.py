@@ -298,3 +298,19 @@ def test_full_size_d1e7_engines_agree_and_properties_hold():
     pick = np.concatenate([np.nonzero(typ == k)[0][:3] for k in range(4)])
     ref, _ = T.oracle_query(nodes, queries[pick], threads=16)
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
+
+
+@pytest.mark.parametrize("name", ["config1_10k_x100", "pad_2k_x200", "v0_5k_x64"])
+def test_baseline_engine_order_matches_baseline_out(name):
+    """BASELINE.json configs[0]: the reference's baseline engine sums sequentially (baseline.hpp:53-64);
+    HVS_ORDER_SCALAR reproduces baseline.out (ids tie-aware, scalar-order distances bit for bit)."""
+    z = np.load(os.path.join(T.GOLDEN_DIR, name + ".npz"))
+    nodes, queries = _inputs(z)
+    with PKG.Engine(0) as e:
+        e.set_distance_order(1)
+        e.load_data(nodes)
+        ids, dists = e.query(queries, 1.0)
+        assert e.last_timing().engine == PKG.ENGINE_EXACT_SCAN
+    T.check_parity(nodes, queries, ids, z["ids_baseline"], got_dists=dists, order="scalar")
+    ref, _ = T.oracle_query(nodes, queries, engine="baseline")
+    T.check_parity(nodes, queries, ids, ref, got_dists=dists, order="scalar")
