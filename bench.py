@@ -61,6 +61,7 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")

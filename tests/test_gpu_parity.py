@@ -314,3 +314,27 @@ def test_baseline_engine_order_matches_baseline_out(name):
     T.check_parity(nodes, queries, ids, z["ids_baseline"], got_dists=dists, order="scalar")
     ref, _ = T.oracle_query(nodes, queries, engine="baseline")
     T.check_parity(nodes, queries, ids, ref, got_dists=dists, order="scalar")
+
+
+def test_clustered_data_parity_both_engines():
+    """Tight Gaussian clusters (distances crowd together, candidate lists fill up): both engines must
+    still agree with the oracle; the MFMA engine may hand some queries to the exact engine."""
+    rng = np.random.default_rng(17)
+    n, nq, ncl = 120_000, 400, 300
+    centers = rng.uniform(-6, 6, (ncl, 100)).astype(np.float32)
+    lab = rng.integers(0, ncl, n)
+    nodes = np.empty((n, 102), np.float32)
+    nodes[:, 2:] = centers[lab] + rng.normal(0, 0.05, (n, 100)).astype(np.float32)
+    nodes[:, 0] = rng.integers(0, 8, n)
+    nodes[:, 1] = rng.random(n, dtype=np.float32)
+    queries = T.gen_queries(nq, 5, ncat=8)
+    queries[:, 4:] = centers[rng.integers(0, ncl, nq)] + rng.normal(0, 0.05, (nq, 100)).astype(np.float32)
+    ref, _ = T.oracle_query(nodes, queries)
+    for engine in (PKG.ENGINE_EXACT_SCAN, PKG.ENGINE_MFMA_FILTER):
+        with PKG.Engine(0) as e:
+            e.set_engine(engine)
+            e.load_data(nodes)
+            ids, dists = e.query(queries, 1.0)
+            t = e.last_timing()
+        T.check_parity(nodes, queries, ids, ref, got_dists=dists)
+        print("engine", engine, "fallback queries", t.fallback_queries, "rescored pairs/query", t.rescored_pairs / nq)
