@@ -422,22 +422,28 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
                        c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                        c->d_bounds, L.K == 0u ? 1 : 0, c->d_out_ids, c->d_out_dists);
-    for (uint32_t level = 1; level <= L.K; ++level) {
-        const uint32_t count = L.off[level + 1] - L.off[level];
-        const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
+    // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on
+    // D=1e6 x 1e4 queries: fewer launches but 3x the candidates per round -- slower, 0.93 vs 1.01 M q/s.)
+    const uint32_t lstep = 1u;
+    for (uint32_t level0 = 1; level0 <= L.K; level0 += lstep) {
+        const uint32_t level1 = std::min(L.K, level0 + lstep - 1u);
         HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
-        if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
-        hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG)), dim3(64 * HVS_WG_WAVES),
-                           0, c->stream, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t, L, level, B,
-                           c->d_counters);
-        if (ev >= 0) {
-            HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
-            c->n_launch_events++;
+        for (uint32_t level = level0; level <= level1; ++level) {
+            const uint32_t count = L.off[level + 1] - L.off[level];
+            const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
+            if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+            hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG)),
+                               dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t, L,
+                               level, B, c->d_counters);
+            if (ev >= 0) {
+                HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
+                c->n_launch_events++;
+            }
         }
         hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
         hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                           c->d_bounds, level == L.K ? 1 : 0, c->d_out_ids, c->d_out_dists);
+                           c->d_bounds, level1 == L.K ? 1 : 0, c->d_out_ids, c->d_out_dists);
     }
     // queries whose candidate lists overflowed are answered again by the exact engine
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
