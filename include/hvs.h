@@ -72,6 +72,11 @@ int hvs_set_engine(hvs_ctx *ctx, int engine);
 #define HVS_ORDER_SIMD 0
 #define HVS_ORDER_SCALAR 1
 int hvs_set_distance_order(hvs_ctx *ctx, int order);
+/* Padding (default on) appends rows n-1, n-2, ... when fewer than 100 rows match
+ * (optimized_parallel.hpp:149-157).  A context that holds only a SHARD of D (D-sharded multi-GPU mode,
+ * sharding.py) turns it off: unmatched slots then carry id 0xFFFFFFFF / distance +inf and the merge of
+ * the shards' partial answers applies the padding once, from the tail of the whole data set. */
+int hvs_set_padding(hvs_ctx *ctx, int enabled);
 
 /* ---- data set D (replaces `nodes`, reference src/test.cpp:71-73 + io.h:111-136) ---------- */
 

@@ -33,6 +33,7 @@ struct hvs_ctx {
     hipStream_t stream = nullptr;
     int engine = HVS_ENGINE_AUTO;
     bool scalar_order = false;  // baseline engine's summation order (exact engine only)
+    bool padding = true;        // pad answers with the last rows of D (off: partial answers of a data shard)
     std::string err;
 
     // data set, raw rows n x 102 (the io.h layout) resident in HBM
@@ -237,10 +238,10 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
     }
     if (c->scalar_order)
         hipLaunchKernelGGL(hvs_k_select<true>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
     else
         hipLaunchKernelGGL(hvs_k_select<false>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->d_out_ids, c->d_out_dists);
+                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -421,7 +422,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
     hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                        c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                       c->d_bounds, L.K == 0u ? 1 : 0, c->d_out_ids, c->d_out_dists);
+                       c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
     // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on
     // D=1e6 x 1e4 queries: fewer launches but 3x the candidates per round -- slower, 0.93 vs 1.01 M q/s.)
     const uint32_t lstep = 1u;
@@ -443,7 +444,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
         hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
         hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                           c->d_bounds, level1 == L.K ? 1 : 0, c->d_out_ids, c->d_out_dists);
+                           c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
     }
     // queries whose candidate lists overflowed are answered again by the exact engine
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
@@ -591,6 +592,13 @@ int hvs_set_engine(hvs_ctx* c, int engine)
         HVS_HIP(c, hipSetDevice(c->device));
         return build_index(c);
     }
+    return HVS_OK;
+}
+
+int hvs_set_padding(hvs_ctx* c, int enabled)
+{
+    if (!c) return HVS_EINVAL;
+    c->padding = enabled != 0;
     return HVS_OK;
 }
 

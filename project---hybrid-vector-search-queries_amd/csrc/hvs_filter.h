@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
 //   => discard iff  s~ < theta := (|q|^2 - tau (1 + 2g)) / 2 - (mu + rho + |q| E_D + e_q NB_D) - slack
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
-                                                   HvsBatch B, const HvsBounds* __restrict__ bounds, int final,
+                                                   HvsBatch B, const HvsBounds* __restrict__ bounds, int final, int pad,
                                                    uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
 {
     __shared__ uint64_t sbuf[4][256];
@@ -945,7 +945,8 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         if (e < HVS_KNN) {
             const uint32_t id = n - 1u - (e - cnt);
             const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
-            buf[e] = hvs_make_key(hvs_exact_dist(dv, qv), id);
+            // padding off (partial answers of a data shard): empty slots hold the largest key
+            buf[e] = pad ? hvs_make_key(hvs_exact_dist(dv, qv), id) : ~0ull;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
             rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
         }
         out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
-        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = hvs_key_dist(ke);
+        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
 }
 

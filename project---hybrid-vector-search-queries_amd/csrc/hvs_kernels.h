@@ -186,7 +186,7 @@ template <bool SCALAR_ORDER>
 __global__ __launch_bounds__(256) void hvs_k_select(
     const float* __restrict__ D, uint32_t n, const float* __restrict__ Q, const uint32_t* __restrict__ qorder,
     uint32_t nq, uint32_t nq_pad, uint32_t nchunks, const uint64_t* __restrict__ cand,
-    const uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+    const uint32_t* __restrict__ cand_cnt, int pad, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
 {
     __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
     const uint32_t lane = threadIdx.x & 63u;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
         if (e < HVS_KNN) {
             const uint32_t id = n - 1u - (e - cnt);
             const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
-            buf[e] = hvs_make_key(SCALAR_ORDER ? hvs_scalar_order_dist(dv, qv) : hvs_exact_dist(dv, qv), id);
+            buf[e] = pad ? hvs_make_key(SCALAR_ORDER ? hvs_scalar_order_dist(dv, qv) : hvs_exact_dist(dv, qv), id) : ~0ull;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -238,6 +238,6 @@ __global__ __launch_bounds__(256) void hvs_k_select(
             rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
         }
         out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
-        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = hvs_key_dist(ke);
+        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
 }

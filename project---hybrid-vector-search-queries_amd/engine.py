@@ -108,6 +108,7 @@ def library():
         "hvs_last_global_error": (C.c_char_p, []),
         "hvs_set_engine": (C.c_int, [vp, C.c_int]),
         "hvs_set_distance_order": (C.c_int, [vp, C.c_int]),
+        "hvs_set_padding": (C.c_int, [vp, C.c_int]),
         "hvs_load_data": (C.c_int, [vp, _f32p, C.c_uint32]),
         "hvs_gen_data": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32]),
         "hvs_download_data": (C.c_int, [vp, C.c_uint32, C.c_uint32, _f32p]),
@@ -172,6 +173,10 @@ class Engine:
     def set_distance_order(self, order):
         """0 = the hot path's SIMD order (default), 1 = the baseline engine's sequential order."""
         self._ck(self._lib.hvs_set_distance_order(self._h, order))
+
+    def set_padding(self, enabled):
+        """Off: answers of a data shard keep id 0xFFFFFFFF / distance +inf in unmatched slots."""
+        self._ck(self._lib.hvs_set_padding(self._h, int(bool(enabled))))
 
     # --- data
     def load_data(self, rows):

@@ -45,3 +45,82 @@ def run_sharded(answer, queries: np.ndarray, group=None, device="cpu"):
     ids = np.ascontiguousarray(answer(queries[q0:q1]), np.uint32)
     t = torch.from_numpy(ids.view(np.int32)).to(device)
     return gather_ids(t, queries.shape[0], group).cpu().numpy().view(np.uint32)
+
+
+# ----------------------------------------------------------------------------------------------
+# D-sharded mode: for data sets larger than one GPU's HBM the ROWS are partitioned
+# instead of the queries.  Every rank answers all queries against its contiguous row range with
+# padding switched off (hvs_set_padding(ctx, 0)); the partial top-100 lists are exchanged and merged
+# -- the multi-GPU counterpart of Knn::merge (reference include/optimized_impl.h:337-385) -- and the
+# padding of include/optimized_parallel.hpp:149-157 is applied once, from the tail of the whole set.
+# ----------------------------------------------------------------------------------------------
+
+EMPTY_ID = np.uint32(0xFFFFFFFF)
+_EMPTY_KEY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def row_shard_range(n: int, rank: int, world: int):
+    """Contiguous row range of a rank; every shard must keep >= 100 rows (hvs_load_data's precondition)."""
+    return shard_range(n, rank, world)
+
+
+def _keys(ids, dists, row0):
+    ids = np.asarray(ids, np.uint32)
+    d = np.ascontiguousarray(dists, np.float32).view(np.uint32).astype(np.uint64)
+    k = (d << np.uint64(32)) | (ids.astype(np.uint64) + np.uint64(row0))
+    return np.where(ids == EMPTY_ID, _EMPTY_KEY, k)
+
+
+def merge_data_shards(parts, n_total: int, pad_dists):
+    """parts: list of (ids_local [nq,100] u32, dists [nq,100] f32, row0) -- one per shard, padding off.
+    pad_dists: [nq,100] f32, pad_dists[q, s] = exact-order distance of query q to row n_total-1-s.
+    Returns (ids [nq,100] u32 global, dists [nq,100] f32) in the canonical order (dist asc, id asc)."""
+    allk = np.concatenate([_keys(i, d, r0) for i, d, r0 in parts], axis=1)
+    allk.sort(axis=1)
+    best = allk[:, :100].copy()
+    m = (best != _EMPTY_KEY).sum(axis=1)
+    pad_ids = (np.uint64(n_total - 1) - np.arange(100, dtype=np.uint64))[None, :]
+    padk = (np.ascontiguousarray(pad_dists, np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | pad_ids
+    for q in np.nonzero(m < 100)[0]:
+        need = 100 - int(m[q])
+        row = np.concatenate([best[q, : m[q]], padk[q, :need]])  # rows n-1, n-2, ... regardless of duplicates
+        row.sort()
+        best[q] = row
+    ids = (best & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    dists = (best >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    return ids, dists
+
+
+def tail_pad_dists(answer_tail, queries):
+    """Distances of every query to the last 100 rows of the whole data set.  `answer_tail(q_rows)`
+    answers against a data set made of exactly those 100 rows (ids 0..99 = rows n-100..n-1); the
+    queries' predicates are stripped so that all 100 rows are returned."""
+    q = np.array(queries, np.float32, copy=True)
+    q[:, 0] = 0.0
+    q[:, 1:4] = -1.0
+    ids, dists = answer_tail(q)
+    out = np.empty(dists.shape, np.float32)
+    # row n-1-s is tail row 99-s
+    np.put_along_axis(out, (99 - ids.astype(np.int64)), dists, axis=1)
+    return out
+
+
+def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None, device="cpu"):
+    """Every rank: ids/dists of ALL queries on its row shard (padding off).  All ranks return the merged
+    global answer.  `pad_dists` must be the same on every rank (broadcast it from the tail's owner)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    ids, dists = answer_shard(queries)
+    ids_t = torch.from_numpy(np.ascontiguousarray(ids, np.uint32).view(np.int32)).to(device)
+    d_t = torch.from_numpy(np.ascontiguousarray(dists, np.float32)).to(device)
+    r0_t = torch.tensor([row0], dtype=torch.int64, device=device)
+    ids_all = torch.empty((world,) + tuple(ids_t.shape), dtype=ids_t.dtype, device=device)
+    d_all = torch.empty((world,) + tuple(d_t.shape), dtype=d_t.dtype, device=device)
+    r0_all = torch.empty((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(ids_all, ids_t, group=group)
+    dist.all_gather_into_tensor(d_all, d_t, group=group)
+    dist.all_gather_into_tensor(r0_all, r0_t, group=group)
+    parts = [(ids_all[r].cpu().numpy().view(np.uint32), d_all[r].cpu().numpy(), int(r0_all[r])) for r in range(world)]
+    return merge_data_shards(parts, n_total, pad_dists)

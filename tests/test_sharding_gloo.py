@@ -45,3 +45,39 @@ def test_two_rank_gloo_run_matches_single_process(tmp_path, nq):
     for r in range(2):
         got = np.load(tmp_path / f"ids{r}.npy")
         assert np.array_equal(got, want), f"rank {r} sees a different gathered result"
+
+
+def _brute_partial(nodes, queries, row0, row1):
+    """Top-100 of a row shard without padding, from exact-order distances (oracle arithmetic)."""
+    nq = queries.shape[0]
+    ids = np.full((nq, 100), 0xFFFFFFFF, np.uint32)
+    dists = np.full((nq, 100), np.inf, np.float32)
+    rows = np.arange(row0, row1, dtype=np.uint32)
+    for q in range(nq):
+        ok = rows[T._passes(nodes[row0:row1], queries[q])]
+        if ok.size == 0:
+            continue
+        d = np.concatenate([T.oracle_dists_for_ids(nodes, queries[q:q + 1], np.resize(ok[i:i + 100], 100)[None, :])[0][:min(100, ok.size - i)]
+                            for i in range(0, ok.size, 100)])
+        order = np.lexsort((ok, d))[:100]
+        ids[q, :order.size] = ok[order] - row0
+        dists[q, :order.size] = d[order]
+    return ids, dists
+
+
+def test_data_sharded_merge_matches_the_whole_set_answer():
+    """D-sharded mode: partial top-100 lists of 3 row shards (no padding) + one padding pass from the
+    tail of the whole set = the answer on the whole set (incl. queries that match < 100 rows)."""
+    n, nq, world = 1500, 48, 3
+    nodes, queries = T.gen_data(n, 21, T.GEN_V1, 30), T.gen_queries(nq, 22, T.GEN_V1, 30)
+    parts = []
+    for r in range(world):
+        r0, r1 = sharding.row_shard_range(n, r, world)
+        i, d = _brute_partial(nodes, queries, r0, r1)
+        parts.append((i, d, r0))
+    tail = np.arange(n - 1, n - 101, -1, dtype=np.uint32)
+    pad = T.oracle_dists_for_ids(nodes, queries, np.tile(tail, (nq, 1)))
+    ids, dists = sharding.merge_data_shards(parts, n, pad)
+    want, want_d = T.oracle_query(nodes, queries)
+    assert np.array_equal(ids, want) and np.array_equal(dists.view(np.uint32), want_d.view(np.uint32))
+    assert any(int(T._passes(nodes, q).sum()) < 100 for q in queries), "the case must exercise padding"
