@@ -417,7 +417,7 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
 
 // per slot: position range of the predicate, norms, bound inputs; resets the top-k state
 __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
-                                 const uint64_t* __restrict__ keys_t, uint32_t n,
+                                 const uint64_t* __restrict__ keys_t, uint32_t n, int count_pairs,
                                  unsigned long long* __restrict__ counters)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,7 +436,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
             e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
             nb2 += (double)xb * (double)xb;
         }
-        atomicAdd(&counters[0], (unsigned long long)(b - a));
+        if (count_pairs) atomicAdd(&counters[0], (unsigned long long)(b - a));
     }
     B.ra[s] = a;
     B.rb[s] = b;
@@ -588,6 +588,115 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
     }
     B.candcnt[slot] = cnt;
     if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nscan);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_scan_ranges -- the exact engine on top of the index: the same lane-per-query, scalar-row
+// kernel as hvs_k_scan_exact, but a wave walks only the POSITION RANGE of its 64 queries (the
+// union of their predicate ranges in the (C,T) or T ordering) instead of all of D, and the per-lane
+// predicate is a position-range test.  Type-1/3 queries then touch ~1 % / 0.25 % of the rows and a
+// type-2 wave touches only rows that some of its queries want.  grid.y cuts the range into chunks.
+// With sn < n (sample_proportion < 1) rows whose original id is >= sn are skipped.
+// ---------------------------------------------------------------------------------------------
+template <bool SCALAR_ORDER>
+__global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restrict__ D, uint32_t sn,
+                                                            const float* __restrict__ Q, HvsBatch B,
+                                                            const uint32_t* __restrict__ perm_ct,
+                                                            const uint32_t* __restrict__ perm_t, uint32_t nchunks,
+                                                            uint32_t slot_begin, uint32_t slot_end, uint64_t* __restrict__ cand,
+                                                            uint32_t* __restrict__ cand_cnt,
+                                                            unsigned long long* __restrict__ counters)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = w * 64u + lane;
+    if (w * 64u >= slot_end || w * 64u + 64u <= slot_begin) return;
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t* __restrict__ perm = perm_ct;  // only (C,T)-ordering classes (types 1, 3) are routed here
+    (void)perm_t;
+
+    // slots outside [slot_begin, slot_end) are type-0 / type-2 queries: answered by the sequential full scan
+    const uint32_t qi = (slot >= slot_begin && slot < slot_end) ? B.qid[slot] : 0xFFFFFFFFu;
+    const bool have_q = qi != 0xFFFFFFFFu;
+    const float* __restrict__ qrow = Q + (size_t)(have_q ? qi : 0u) * HVS_QCOLS;
+    const uint32_t ra = have_q ? B.ra[slot] : 0u, rb = have_q ? B.rb[slot] : 0u;
+    // union of this wave's ranges (64 slots; the group's union would also cover the other half)
+    uint32_t ua = ra < rb ? ra : 0xFFFFFFFFu, ub = ra < rb ? rb : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t oa = __shfl_xor(ua, o), ob = __shfl_xor(ub, o);
+        ua = oa < ua ? oa : ua;
+        ub = ob > ub ? ob : ub;
+    }
+    ua = __builtin_amdgcn_readfirstlane(ua);
+    ub = __builtin_amdgcn_readfirstlane(ub);
+    if (ua >= ub) return;
+    const uint32_t len = hvs_ceil_div(ub - ua, nchunks);
+    const uint32_t p0 = ua + chunk * len;
+    const uint32_t p1 = (p0 + len) < ub ? (p0 + len) : ub;
+    if (p0 >= p1) return;
+
+    hvs_f2 q2[HVS_NDIM / 2];
+#pragma unroll
+    for (int i = 0; i < HVS_NDIM / 4; ++i) {
+        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 4 * i);
+        q2[2 * i] = hvs_f2{v4.x, v4.y};
+        q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
+    }
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * B.nslots + slot) * 256u;
+    float tau = __builtin_inff();
+    uint32_t cnt = 0, nscan = 0;
+    for (uint32_t pos = p0; pos < p1; ++pos) {
+        const bool pass = pos >= ra && pos < rb;
+        if (__ballot(pass) == 0ull) continue;
+        const uint32_t id = perm[pos];
+        if (id >= sn) continue;  // sampled prefix: rows [0, sn) of the original order only
+        nscan += 64u;
+        const float* __restrict__ row = D + (size_t)id * HVS_DCOLS + 2;
+        float dist;
+        if (SCALAR_ORDER) {
+            struct R1 { const float* __restrict__ p; __device__ __forceinline__ float operator[](int i) const { return p[i]; } } d1{row};
+            struct Q1 { const hvs_f2* q; __device__ __forceinline__ float operator[](int i) const { return (i & 1) ? q[i >> 1].y : q[i >> 1].x; } } q1{q2};
+            dist = hvs_scalar_order_dist(d1, q1);
+        } else {
+            HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(row)};
+            dist = hvs_exact_dist_pk(dv, q2);
+        }
+        if (pass && dist <= tau) {  // ids are not monotone along a position range: keep ties, the keys sort them out
+            mylist[cnt] = hvs_make_key(dist, id);
+            ++cnt;
+        }
+        uint64_t full = __ballot(cnt == 256u);
+        if (full != 0ull) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            while (full != 0ull) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(full);
+                full &= full - 1ull;
+                uint64_t* lst = cand + ((size_t)chunk * B.nslots + (w * 64u + l)) * 256u;
+                const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, 256u, lane);
+                if (lane == l) {
+                    cnt = HVS_KNN;
+                    tau = hvs_key_dist(kth);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    if (have_q) cand_cnt[(size_t)chunk * B.nslots + slot] = cnt;
+    if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nscan);
+}
+
+// passing pairs of a sampled prefix (sn < n): the position range over-counts, so count ids < sn exactly
+__global__ void hvs_k_count_prefix_pairs(HvsBatch B, const uint32_t* __restrict__ perm_ct, const uint32_t* __restrict__ perm_t,
+                                         uint32_t sn, unsigned long long* __restrict__ counters)
+{
+    const uint32_t slot = blockIdx.x;
+    if (B.qid[slot] == 0xFFFFFFFFu) return;
+    const uint32_t* __restrict__ perm = B.gord[slot / HVS_GROUP] ? perm_t : perm_ct;
+    uint32_t c = 0;
+    for (uint32_t pos = B.ra[slot] + threadIdx.x; pos < B.rb[slot]; pos += blockDim.x) c += perm[pos] < sn ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&counters[0], (unsigned long long)c);
 }
 
 // ---------------------------------------------------------------------------------------------

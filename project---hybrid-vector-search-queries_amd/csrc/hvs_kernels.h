@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
     if (slot >= nq) return;  // wave-uniform
     uint64_t* buf = sbuf[w];
     const uint32_t qi = qorder[slot];
+    if (qi == 0xFFFFFFFFu) return;  // padding slot of the range-scan layout
 
     uint32_t cnt = 0;
     for (uint32_t c = 0; c < nchunks; ++c) {
