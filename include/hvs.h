@@ -39,7 +39,7 @@ typedef struct hvs_ctx hvs_ctx;
 /* Engines.  HVS_ENGINE_AUTO picks the fastest exact engine for the loaded data. */
 #define HVS_ENGINE_AUTO 0
 #define HVS_ENGINE_EXACT_SCAN 1 /* FP32 exact-order scan of every candidate row (VALU)       */
-#define HVS_ENGINE_MFMA_FILTER 2 /* BF16 MFMA bound filter + exact-order re-scoring            */
+#define HVS_ENGINE_MFMA_FILTER 2 /* BF16 MFMA bound filter + exact-order re-scoring (same answers) */
 
 typedef struct hvs_timing {
     double query_ms;      /* whole vec_query-equivalent region on the device stream (HIP events)   */

@@ -487,15 +487,18 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     return HVS_OK;
 }
 
-int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
+int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 {
-    int rc = prep_batch(c, q0, nqb, true);
+    int rc = prep_batch(c, q0, nqb, sn == c->n);
     if (rc) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
     const uint32_t n = c->n;
+    if (sn != n)
+        hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
+                           c->d_counters);
 
-    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, sn, c->d_q, B,
                        c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                        c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
@@ -517,7 +520,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
                 c->n_launch_events++;
             }
         }
-        hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, c->d_q, B, c->d_perm_ct,
+        hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
         hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                            c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
@@ -534,7 +537,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb)
         c->fallback_queries += novf;
         for (uint32_t off = 0; off < novf; off += kBatch) {
             const uint32_t m = std::min(kBatch, novf - off);
-            if ((rc = run_batch_exact(c, 0, m, n, c->d_ovf_list + off, false, false))) return rc;
+            if ((rc = run_batch_exact(c, 0, m, sn, c->d_ovf_list + off, false, false))) return rc;
         }
     }
     return HVS_OK;
@@ -546,8 +549,10 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
     HVS_HIP(c, hipSetDevice(c->device));
     const uint32_t sn = sample_rows(sample_proportion, c->n);
-    // the index orders ALL rows; a sampled prefix [0,sn) is answered by the exact engine
-    bool mfma = c->have_index && sn == c->n && !c->scalar_order &&
+    // The index orders ALL rows: with a sampled prefix [0,sn) the filter still proposes rows >= sn and the
+    // exact stages drop them, so its candidate lists grow by n/sn -- used down to sn = n/4, below that
+    // the exact engine answers.
+    bool mfma = c->have_index && sn >= c->n / 4u && sn > 0u && !c->scalar_order &&
                 (c->engine == HVS_ENGINE_MFMA_FILTER || (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
     c->timing_valid = false;
     c->n_launch_events = 0;
@@ -558,7 +563,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     const uint32_t step = mfma ? kBatchMfma : kBatch;
     for (uint32_t off = 0; off < nq; off += step) {
         const uint32_t nqb = std::min(step, nq - off);
-        int rc = mfma ? run_batch_mfma(c, q0 + off, nqb)
+        int rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
                       : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
         if (rc) return rc;
     }

@@ -519,7 +519,7 @@ struct HvsUniformRowF2 {
     __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
 };
 
-__global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restrict__ D, uint32_t n,
+__global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restrict__ D, uint32_t n, uint32_t sn,
                                                            const float* __restrict__ Q, HvsBatch B,
                                                            const uint32_t* __restrict__ perm_ct,
                                                            const uint32_t* __restrict__ perm_t,
@@ -561,8 +561,9 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
             if (pos >= n) break;
             const bool pass = pos >= ra && pos < rb;
             if (__ballot(pass) == 0ull) continue;
-            nscan += 64u;
             const uint32_t id = perm[pos];
+            if (id >= sn) continue;  // sampled prefix: rows [0, sn) of the original order only
+            nscan += 64u;
             HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(D + (size_t)id * HVS_DCOLS + 2)};
             const float dist = hvs_exact_dist_pk(dv, q2);
             if (pass && dist <= tau) {
@@ -921,8 +922,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // hvs_k_rescore -- exact-order distances of the filter's survivors: one lane per (slot,pos) pair,
 // the same arithmetic as everywhere else (hvs_exact_dist), key appended to the slot's list.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, const float* __restrict__ Q, HvsBatch B,
-                                                     const uint32_t* __restrict__ perm_ct,
+__global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
+                                                     HvsBatch B, const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
                                                      unsigned long long* __restrict__ counters)
 {
@@ -954,6 +955,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
         const uint64_t pr = B.pairs[(size_t)g * HVS_GCAP + e];
         const uint32_t slot = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
         const uint32_t id = perm[pos];
+        if (id >= sn) continue;  // sampled prefix (sample_proportion < 1): the filter does not know about it
         const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
         const float* qv = &sq[slot - g * HVS_GROUP][0];
         const float dist = hvs_exact_dist(dv, qv);

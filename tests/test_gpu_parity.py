@@ -188,11 +188,16 @@ def test_mfma_engine_levels_and_ranges(n):
         T.check_parity(nodes, queries, ids, ref, got_dists=dists)
         passing = sum(int(T._passes(nodes, q).sum()) for q in queries)
         assert t.pairs == passing
-        # a sampled prefix is answered by the exact engine (the index orders all rows)
-        ids2, d2 = e.query(queries[:40], 0.25)
-        assert e.last_timing().engine == PKG.ENGINE_EXACT_SCAN
-        ref2, _ = T.oracle_query(nodes, queries[:40], 0.25)
-        T.check_parity(nodes, queries[:40], ids2, ref2, sample_proportion=0.25, got_dists=d2)
+        # sampled prefixes: the filter engine down to sn = n/4 (its exact stages drop rows >= sn), the exact
+        # engine below that
+        for sp, want_engine in ((0.6, PKG.ENGINE_MFMA_FILTER), (0.3, PKG.ENGINE_MFMA_FILTER), (0.1, PKG.ENGINE_EXACT_SCAN)):
+            ids2, d2 = e.query(queries[:80], sp)
+            t2 = e.last_timing()
+            assert t2.engine == want_engine, (sp, t2.engine)
+            ref2, _ = T.oracle_query(nodes, queries[:80], sp)
+            T.check_parity(nodes, queries[:80], ids2, ref2, sample_proportion=sp, got_dists=d2)
+            sn = int(T.oracle().hvs_oracle_sn(sp, n))
+            assert t2.pairs == sum(int(T._passes(nodes[:sn], q).sum()) for q in queries[:80])
 
 
 def test_mfma_engine_overflow_falls_back_to_exact():
