@@ -22,10 +22,6 @@ namespace {
 
 thread_local std::string g_global_err;
 
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
 }  // namespace
 
 struct hvs_ctx {

@@ -153,8 +153,6 @@ __device__ __forceinline__ uint64_t hvs_make_key(float dist, uint32_t id)
 __device__ __forceinline__ float hvs_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t hvs_key_id(uint64_t key) { return (uint32_t)key; }
 
-__device__ __forceinline__ uint32_t hvs_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ uint32_t hvs_prefix_count(uint64_t mask)
 {

@@ -76,7 +76,6 @@ __host__ __device__ static inline uint32_t hvs_attr_key(float f)
 #endif
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-#define HVS_KEY_POS_INF 0xFF800000u  // hvs_attr_key(+inf): upper bound of every non-NaN value
 
 __device__ __forceinline__ uint16_t hvs_bf16_bits(float f)
 {
