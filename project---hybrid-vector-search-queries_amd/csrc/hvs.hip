@@ -92,6 +92,8 @@ uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi)
 // queries answered per pass over D; HVS_EXACT_BATCH / HVS_MFMA_BATCH override (tests use small batches)
 const uint32_t kBatch = env_u32("HVS_EXACT_BATCH", 65536u, 64u, 1u << 20);
 const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 262144u, 128u, 1u << 20);
+// exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
+const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
 
@@ -221,14 +223,23 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
     const int ev = (record_events && c->n_launch_events < hvs_ctx::kMaxLaunchEvents) ? c->n_launch_events : -1;
     if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
     if (sn > 0) {
-        if (c->scalar_order)
-            hipLaunchKernelGGL(hvs_k_scan_exact<true>, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream,
-                               c->d_data, c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
-                               count_stats ? c->d_counters : c->d_counters + 4);
-        else
-            hipLaunchKernelGGL(hvs_k_scan_exact<false>, dim3(p.nq_pad / 256u, p.nchunks), dim3(256), 0, c->stream,
-                               c->d_data, c->d_q, qorder, nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt,
-                               count_stats ? c->d_counters : c->d_counters + 4);
+        unsigned long long* stat = count_stats ? c->d_counters : c->d_counters + 4;
+        const dim3 grid(p.nq_pad / 256u, p.nchunks);
+        if (kScanRowsThroughLds) {
+            if (c->scalar_order)
+                hipLaunchKernelGGL(hvs_k_scan_exact_lds<true>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
+            else
+                hipLaunchKernelGGL(hvs_k_scan_exact_lds<false>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
+        } else {
+            if (c->scalar_order)
+                hipLaunchKernelGGL(hvs_k_scan_exact<true>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
+            else
+                hipLaunchKernelGGL(hvs_k_scan_exact<false>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
+        }
     }
     if (ev >= 0) {
         HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
@@ -713,6 +724,13 @@ static int finish_data(hvs_ctx* c)
     if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER) return HVS_OK;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     int rc = build_index(c);
+    if (rc == HVS_ENOMEM) {
+        // not enough HBM for the index next to D: the data set stays usable through the exact engine
+        (void)hipGetLastError();
+        free_index(c);
+        c->err = "index not built (out of device memory): exact engine only";
+        rc = HVS_OK;
+    }
     if (rc) return rc;
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));

@@ -175,6 +175,156 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
 }
 
 // ---------------------------------------------------------------------------------------------
+// hvs_k_scan_exact_lds -- the same scan with the data rows staged in LDS instead of SGPRs.
+// The four waves of a workgroup (256 queries) walk the same row chunk, so a block of 32 rows is
+// copied once per workgroup (coalesced 16-B loads, double-buffered, one barrier per 32 rows) into a
+// 16-B aligned image [x0..x99, C, T, pad, pad] and every wave reads it back with broadcast
+// ds_read_b128.  This removes the scalar-load round trips of hvs_k_scan_exact from the row loop
+// (two dependent s_load + s_waitcnt per row there); arithmetic and admission are identical.
+// ---------------------------------------------------------------------------------------------
+#define HVS_LDS_ROWS 32
+#define HVS_LDS_ROW_F 104  // floats per staged row (416 B, 16-B aligned)
+
+struct HvsLdsRow2 {
+    const float4* p;  // 16-B aligned row image in LDS
+    __device__ __forceinline__ hvs_f2 operator[](int i) const
+    {
+        const float4 v = p[i >> 1];
+        return (i & 1) ? hvs_f2{v.z, v.w} : hvs_f2{v.x, v.y};
+    }
+};
+struct HvsLdsRow1 {
+    const float* p;
+    __device__ __forceinline__ float operator[](int i) const { return p[i]; }
+};
+
+template <bool SCALAR_ORDER>
+__global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
+    const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
+    uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+    unsigned long long* __restrict__ counters)
+{
+    __shared__ float4 srow[2][HVS_LDS_ROWS * HVS_LDS_ROW_F / 4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t qwave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = qwave * 64u + lane;
+    const uint32_t chunk = blockIdx.y;
+    const bool wave_active = qwave * 64u < nq;  // inactive waves still help staging and meet the barriers
+
+    const bool have_q = slot < nq;
+    const uint32_t qi = qorder[have_q ? slot : (nq - 1u)];
+    const float* __restrict__ qrow = Q + (size_t)qi * HVS_QCOLS;
+    HvsQParams p = hvs_parse_query(qrow);
+    if (!have_q) p.type = 4u;
+    hvs_f2 q2[HVS_NDIM / 2];
+#pragma unroll
+    for (int i = 0; i < HVS_NDIM / 4; ++i) {
+        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 4 * i);
+        q2[2 * i] = hvs_f2{v4.x, v4.y};
+        q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
+    }
+
+    const uint32_t r0 = chunk * rows_per_chunk;
+    uint32_t r1 = r0 + rows_per_chunk;
+    if (r1 > sn || r1 < r0) r1 = sn;
+    if (r0 >= r1) return;  // uniform over the workgroup
+
+    // staging: item e = (row r, piece c): c < 25 -> floats 2+4c..5+4c of the row, c == 25 -> (C, T, 0, 0)
+    constexpr uint32_t kItems = HVS_LDS_ROWS * 26u;
+    float4 stg[(kItems + 255u) / 256u];
+    auto load_block = [&](uint32_t j0) {
+#pragma unroll
+        for (uint32_t k = 0; k < (kItems + 255u) / 256u; ++k) {
+            const uint32_t e = threadIdx.x + 256u * k;
+            const uint32_t r = e / 26u, c = e % 26u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < kItems && j0 + r < r1) {
+                const float* __restrict__ src = D + (size_t)(j0 + r) * HVS_DCOLS;
+                if (c < 25u) {
+                    const float2 a = *reinterpret_cast<const float2*>(src + 2 + 4 * c);
+                    const float2 b = *reinterpret_cast<const float2*>(src + 4 + 4 * c);
+                    v = make_float4(a.x, a.y, b.x, b.y);
+                } else {
+                    const float2 a = *reinterpret_cast<const float2*>(src);
+                    v = make_float4(a.x, a.y, 0.f, 0.f);
+                }
+            }
+            stg[k] = v;
+        }
+    };
+    auto store_block = [&](uint32_t buf) {
+#pragma unroll
+        for (uint32_t k = 0; k < (kItems + 255u) / 256u; ++k) {
+            const uint32_t e = threadIdx.x + 256u * k;
+            if (e < kItems) srow[buf][(e / 26u) * (HVS_LDS_ROW_F / 4) + (e % 26u)] = stg[k];
+        }
+    };
+
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
+    float tau = __builtin_inff();
+    uint32_t cnt = 0;
+    uint32_t npass = 0, nscan = 0;
+
+    load_block(r0);
+    store_block(0u);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t j0 = r0; j0 < r1; j0 += HVS_LDS_ROWS) {
+        const bool more = j0 + HVS_LDS_ROWS < r1;
+        if (more) load_block(j0 + HVS_LDS_ROWS);
+        if (wave_active) {
+            const uint32_t nrow = (r1 - j0) < HVS_LDS_ROWS ? (r1 - j0) : HVS_LDS_ROWS;
+            for (uint32_t r = 0; r < nrow; ++r) {
+                const float4* rowp = &srow[buf][r * (HVS_LDS_ROW_F / 4)];
+                const float4 attr = rowp[25];
+                const bool pass = hvs_row_passes(p, attr.x, attr.y);
+                const uint64_t pmask = __ballot(pass);
+                if (pmask == 0ull) continue;
+                npass += (uint32_t)__popcll(pmask);
+                nscan += 64u;
+                float dist;
+                if (SCALAR_ORDER) {
+                    HvsLdsRow1 d1{reinterpret_cast<const float*>(rowp)};
+                    HvsPairAsScalar q1{q2};
+                    dist = hvs_scalar_order_dist(d1, q1);
+                } else {
+                    // packed f32 math: measured 14.0 k type-0 queries/s at D=1e7 against 12.5 k with the 300 unpacked ops
+                    HvsLdsRow2 dv{rowp};
+                    dist = hvs_exact_dist_pk(dv, q2);
+                }
+                if (pass && dist < tau) {
+                    mylist[cnt] = hvs_make_key(dist, j0 + r);
+                    ++cnt;
+                }
+                uint64_t full = __ballot(cnt == HVS_CAND_CAP);
+                if (full != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    while (full != 0ull) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(full);
+                        full &= full - 1ull;
+                        uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * HVS_CAND_CAP;
+                        const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, HVS_CAND_CAP, lane);
+                        if (lane == l) {
+                            cnt = HVS_KNN;
+                            tau = hvs_key_dist(kth);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
+        }
+        if (more) store_block(buf ^ 1u);
+        __syncthreads();
+        buf ^= 1u;
+    }
+    if (have_q) cand_cnt[(size_t)chunk * nq_pad + slot] = cnt;
+    if (wave_active && lane == 0u) {
+        atomicAdd(&counters[0], (unsigned long long)npass);
+        atomicAdd(&counters[1], (unsigned long long)nscan);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // hvs_k_select -- per query: merge the per-chunk candidate lists (the counterpart of
 // Knn::merge, optimized_impl.h:337-385 + optimized_parallel.hpp:142-146), pad with the last
 // rows of D when fewer than 100 rows matched (optimized_parallel.hpp:149-157: rows n-1, n-2,
