@@ -1,0 +1,55 @@
+"""Differential fuzzing on a GPU box: the MFMA engine must return the exact engine's bits (ids AND
+distances) for random data shapes, category counts, value ranges, special attribute values, query
+mixes and sample proportions.  Prints one line per case; exits 1 on the first mismatch."""
+import importlib, sys, time
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import hvs_testlib as T
+PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
+
+def case(rng, i):
+    n = int(rng.choice([100, 101, 1000, 4095, 4096, 5000, 33000, 70000, 200000, 1000003]))
+    nq = int(rng.choice([1, 31, 33, 128, 129, 1000, 5000]))
+    ncat = int(rng.choice([1, 2, 7, 100, 5000]))
+    profile = int(rng.choice([0, 1, 1, 1]))
+    nodes = T.gen_data(n, int(rng.integers(1 << 30)), profile, ncat)
+    queries = T.gen_queries(nq, int(rng.integers(1 << 30)), profile, ncat)
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 50.0]))
+    nodes[:, 2:] *= np.float32(scale); queries[:, 4:] *= np.float32(scale)
+    if rng.random() < 0.3:   # clustered vectors / duplicates
+        base = nodes[rng.integers(0, n, max(2, n // 50)), 2:]
+        nodes[:, 2:] = base[rng.integers(0, base.shape[0], n)] + rng.normal(0, 0.01 * scale, (n, 100)).astype(np.float32) * (rng.random() < 0.5)
+    if rng.random() < 0.3:
+        k = max(1, n // 97)
+        nodes[rng.integers(0, n, k), 1] = np.nan
+        nodes[rng.integers(0, n, k), 0] = np.nan
+        nodes[rng.integers(0, n, k), 1] = rng.choice([-0.0, 0.0, np.inf, -np.inf], k)
+    if rng.random() < 0.3 and nq >= 8:
+        queries[0, :4] = [2, -1, 0.7, 0.2]; queries[1, :4] = [3, 0, -np.inf, np.inf]; queries[2, 0] = 9
+        queries[3, :4] = [2, -1, np.nan, 1]; queries[4, :4] = [1, -0.0, -1, -1]; queries[5, :4] = [3, 1, 0.3, 0.3]
+    sp = float(rng.choice([1.0, 1.0, 1.0, 0.9, 0.5, 0.26, 0.1]))
+    res = []
+    for engine in (1, 2):
+        with PKG.Engine(0) as e:
+            e.set_engine(engine); e.load_data(nodes)
+            ids, d = e.query(queries, sp); t = e.last_timing()
+        res.append((ids, d, t.engine, t.fallback_queries))
+    same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} engines={res[0][2]},{res[1][2]} fallback={res[1][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
+    if not same:
+        bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1))[0]
+        print("  first bad queries:", bad[:10], queries[bad[:3], :4]); np.savez("gpurun_out/fuzz_fail.npz", nodes=nodes, queries=queries, sp=sp)
+    if n <= 5000 and nq <= 129:   # small cases also against the oracle
+        ref, _ = T.oracle_query(nodes, queries, sp)
+        T.check_parity(nodes, queries, res[1][0], ref, sample_proportion=sp, got_dists=res[1][1])
+    return same
+
+if __name__ == "__main__":
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); i = 0
+    while time.time() - t0 < budget:
+        if not case(rng, i): sys.exit(1)
+        i += 1
+    print(f"FUZZ-OK {i} cases")
