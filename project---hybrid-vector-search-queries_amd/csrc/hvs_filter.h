@@ -979,7 +979,8 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
 //        s~  = MFMA value of  bf16(q).bf16(d) + h0+h1+h2,     h ~ -|d|^2/2
 //        mu  = bound on the MFMA accumulation error, rho = |  |d|^2/2 + h0+h1+h2 |
 //        |q.d - bf16(q).bf16(d)| <= |q| E_D + e_q NB_D   (Cauchy-Schwarz; E_D, NB_D row maxima)
-//   => discard iff  s~ < theta := (|q|^2 - tau (1 + 2g)) / 2 - (mu + rho + |q| E_D + e_q NB_D) - slack
+//   => discard iff  s~ < theta := (|q|^2 - tau (1 + 2g)) / 2 - (mu + rho + |q| E_D + e_q NB_D) - slack,
+//      slack = 1e-9 (|q|^2 + tau + band) covering the f64 evaluation of theta itself
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
                                                    HvsBatch B, const HvsBounds* __restrict__ bounds, int final, int pad,
@@ -1035,7 +1036,10 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                 const double mu = 256.0 * 5.9604644775390625e-08 * sabs;
                 const double band = mu + (double)bounds->rho + (double)B.normq[slot] * (double)bounds->e_d +
                                     (double)B.eq[slot] * (double)bounds->nb_d;
-                const double th = 0.5 * (B.qn[slot] * (1.0 - 1e-12) - (double)tau * (1.0 + 2.0 * g)) - band * (1.0 + 1e-6) - 1e-3;
+                // slack for the f64 evaluation itself: relative to the magnitudes involved (an absolute constant
+                // would swamp data whose distances are tiny, e.g. vectors scaled by 1e-3)
+                const double slack = 1e-9 * (B.qn[slot] + (double)tau + band);
+                const double th = 0.5 * (B.qn[slot] * (1.0 - 1e-12) - (double)tau * (1.0 + 2.0 * g)) - band * (1.0 + 1e-6) - slack;
                 float tf = (float)th;
                 if ((double)tf > th) {  // round down
                     if (tf == 0.0f) tf = -1.0e-30f;
