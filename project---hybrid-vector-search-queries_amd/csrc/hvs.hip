@@ -343,7 +343,9 @@ int build_index(hvs_ctx* c)
     HvsBounds hb{};
     HVS_HIP(c, hipMemcpy(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost));
     if (!(std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho)) ||
-        hb.hmax > 1.0e30f) {
+        hb.hmax > 1.0e30f || (hb.hmax > 0.0f && hb.hmax < 1.0e-20f)) {
+        // (norms near the f32 denormal range: BF16 operands might be flushed by the matrix pipe, which the
+        // error bound does not model)
         free_index(c);
         return HVS_OK;
     }
