@@ -566,7 +566,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     c->timing_valid = false;
     c->n_launch_events = 0;
     c->fallback_queries = 0;
-    HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
     const uint32_t step = mfma ? kBatchMfma : kBatch;
@@ -638,7 +638,7 @@ int hvs_create(hvs_ctx** out, int device)
         if ((e = hipEventCreate(&c->ev_k0[i])) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_k1[i])) != hipSuccess) return bail("hipEventCreate", e);
     }
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 8 * sizeof(unsigned long long))) != hipSuccess)
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
     *out = c;
     return HVS_OK;
@@ -908,6 +908,18 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
     c->timing.pairs = h[0];
     c->timing.scanned_pairs = h[1];
     c->timing.rescored_pairs = h[2];
+#ifdef HVS_DIAG_STAMPS
+    {
+        unsigned long long d[16];
+        HVS_HIP(c, hipMemcpy(d, c->d_counters, sizeof(d), hipMemcpyDeviceToHost));
+        if (d[13])
+            std::fprintf(stderr,
+                         "[diag last level] wave cycles: total %.3e  dma-issue %.1f%%  ds_read+mfma+epilogue %.1f%%  survivors %.1f%%  "
+                         "barrier %.1f%%  | per tile: compute %.0f, all %.0f cycles\n",
+                         (double)d[8], 100.0 * d[9] / d[8], 100.0 * d[10] / d[8], 100.0 * d[11] / d[8], 100.0 * d[12] / d[8],
+                         (double)d[10] / d[13], (double)d[8] / d[13]);
+    }
+#endif
     *out = c->timing;
     return HVS_OK;
 }

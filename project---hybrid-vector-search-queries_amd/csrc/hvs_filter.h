@@ -747,8 +747,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
-    const uint32_t lvl_off = L.off[level], lvl_stride = L.stride[level], lvl_radix = L.radix[level];
-    const uint32_t seg_lo = lvl_off + blockIdx.y * HVS_SEG;
+    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
     uint32_t i0 = 0, i1 = 0;  // this wave's tiles [i0,i1) inside the segment (empty when i0 >= i1)
     if (g < B.ngroups && B.gord[g] == ord) {
         uint32_t lo, hi;
@@ -813,9 +812,9 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // waited for its own chunks before any wave passes the barrier) and frees the current buffer
     // (every wave has finished its ds_reads of it).  One barrier per 4 tiles keeps the waves loosely coupled: a
     // wave that spends time on survivors of one tile catches up inside the stage.
-    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
-#pragma unroll
-        for (int k = 0; k < (HVS_STAGE * HVS_KSTEPS + HVS_WG_WAVES - 1) / HVS_WG_WAVES; ++k) {
+    constexpr int kChunksPerWave = (HVS_STAGE * HVS_KSTEPS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
+    auto issue_chunks = [&](uint32_t buf, uint32_t first_tile, int k0, int k1) {
+        for (int k = k0; k < k1; ++k) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + (uint32_t)HVS_WG_WAVES * (uint32_t)k;  // chunk of the stage
             if (c >= HVS_STAGE * HVS_KSTEPS) break;
             uint32_t tile = first_tile + c / HVS_KSTEPS;
@@ -835,6 +834,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                          : "memory");
         }
     };
+    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) { issue_chunks(buf, first_tile, 0, kChunksPerWave); };
     auto stage_barrier = [&]() {
 #ifndef HVS_EXPERIMENT_NOSYNC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA chunks have landed
@@ -842,19 +842,36 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 #endif
     };
     const uint32_t nstage = hvs_ceil_div(I1 - I0, HVS_STAGE);
+#ifdef HVS_DIAG_STAMPS
+    // diagnostic build only (never timed): where a wave's cycles go; sums leave through counters[8..13]
+    unsigned long long tg_dma = 0, tg_comp = 0, tg_slow = 0, tg_bar = 0, tg_tiles = 0, ta, tb, tc, td;
+#define HVS_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long ts_begin;
+    HVS_STAMP(ts_begin);
+#endif
     issue_stage(0u, I0);
     stage_barrier();
     for (uint32_t st = 0; st < nstage; ++st) {
         const uint32_t cur = st & 1u;
+#ifdef HVS_DIAG_STAMPS
+        HVS_STAMP(ta);
+#endif
 #ifndef HVS_EXPERIMENT_NODMA
         if (st + 1u < nstage) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#endif
+#ifdef HVS_DIAG_STAMPS
+        HVS_STAMP(tb);
+        tg_dma += tb - ta;
 #endif
 #pragma unroll 1
         for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
             const uint32_t i = I0 + st * HVS_STAGE + tt;
             if (i >= I1) break;
             if (active && i >= i0 && i < i1) {  // wave-uniform
-                const uint32_t bp = bpos[i];
+#ifdef HVS_DIAG_STAMPS
+                HVS_STAMP(tb);
+#endif
+                const uint32_t bp = bpos[i];  // scalar load; computing it (runtime division by radix-1) measured 4 % slower
                 ++nblocks;
                 hvs_bf16x8 af[HVS_KSTEPS];
     #pragma unroll
@@ -884,6 +901,11 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     #endif
                     anyhit = anyhit | hit[qb];
                 }
+#ifdef HVS_DIAG_STAMPS
+                HVS_STAMP(tc);
+                tg_comp += tc - tb;
+                tg_tiles += 1;
+#endif
                 if (__ballot(anyhit) != 0ull) {
     #pragma unroll
                     for (int qb = 0; qb < HVS_QB; ++qb) {
@@ -907,13 +929,36 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                         }
                     }
                 }
+#ifdef HVS_DIAG_STAMPS
+                HVS_STAMP(td);
+                tg_slow += td - tc;
+#endif
             }
         }
+#ifdef HVS_DIAG_STAMPS
+        HVS_STAMP(tc);
+#endif
         stage_barrier();
+#ifdef HVS_DIAG_STAMPS
+        HVS_STAMP(td);
+        tg_bar += td - tc;
+#endif
     }
     if (active) {
         flush();
         if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
+#ifdef HVS_DIAG_STAMPS
+        unsigned long long ts_end;
+        HVS_STAMP(ts_end);
+        if (lane == 0u && level == L.K) {
+            atomicAdd(&counters[8], ts_end - ts_begin);
+            atomicAdd(&counters[9], tg_dma);
+            atomicAdd(&counters[10], tg_comp);
+            atomicAdd(&counters[11], tg_slow);
+            atomicAdd(&counters[12], tg_bar);
+            atomicAdd(&counters[13], tg_tiles);
+        }
+#endif
     }
 }
 
