@@ -160,6 +160,9 @@ def main():
                          "evaluated_pairs_per_launch": scanned / max(kern_launches, 1),
                          "device_query_ms_per_step": query_ms / a.steps,
                          "rescored_pairs_per_query": rescored / max(a.batch * a.steps, 1),
+                         # context, not the peak: a bare loop of the same MFMA chains sustains this much on random
+                         # BF16 operands on this chip (DVFS; scripts/mfma_loop_lab.hip -DLAB_RANDOM)
+                         "measured_mfma_ceiling_random_operands_tflops": 1592.0 if engine_id == 2 else None,
                          "fallback_queries": fallback},
             "load_s": load_s,
         }

@@ -857,7 +857,13 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         HVS_STAMP(ta);
 #endif
 #ifndef HVS_EXPERIMENT_NODMA
+#ifdef HVS_STAGGER
+        // 8-wave workgroups: the two waves of a SIMD (w and w+4) issue their LDS-DMA in different halves of
+        // the stage, so one of them multiplies while the other feeds the next stage
+        if (st + 1u < nstage && __builtin_amdgcn_readfirstlane(wv) < 4u) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#else
         if (st + 1u < nstage) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#endif
 #endif
 #ifdef HVS_DIAG_STAMPS
         HVS_STAMP(tb);
@@ -867,6 +873,10 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
             const uint32_t i = I0 + st * HVS_STAGE + tt;
             if (i >= I1) break;
+#ifdef HVS_STAGGER
+            if (tt == HVS_STAGE / 2 && st + 1u < nstage && __builtin_amdgcn_readfirstlane(wv) >= 4u)
+                issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+#endif
             if (active && i >= i0 && i < i1) {  // wave-uniform
 #ifdef HVS_DIAG_STAMPS
                 HVS_STAMP(tb);

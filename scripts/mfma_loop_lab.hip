@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TILE_U4 448
@@ -114,9 +115,23 @@ int main(int argc, char** argv)
     uint4 *in, *tiles; float* out;
     std::vector<unsigned> h(35 * 64 * 4);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3F803F80u ^ (unsigned)((i * 2654435761u) & 0x007F007Fu);
+#ifdef LAB_RANDOM
+    // random BF16 operands in [-6,6) like the real tiles (sign, exponent and mantissa bits all toggle)
+    auto rb = [](unsigned long long& st) { st = st * 6364136223846793005ull + 1442695040888963407ull; float f = ((st >> 40) * (1.0f / 16777216.0f)) * 12.0f - 6.0f; unsigned u; memcpy(&u, &f, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; };
+    unsigned long long stt = 12345;
+    for (size_t i = 0; i < h.size(); ++i) { unsigned lo = rb(stt), hi = rb(stt); h[i] = lo | (hi << 16); }
+#endif
     hipMalloc(&in, h.size() * 4); hipMalloc(&out, 4096 * 256 * 4);
     const size_t tile_bytes = (size_t)64 * 4096 * TILE_U4 * 16;  // 1.9 GB of tiles to stream
     hipMalloc(&tiles, tile_bytes); hipMemset(tiles, 0x3c, tile_bytes);
+#ifdef LAB_RANDOM
+    {
+        std::vector<unsigned> big(64u << 20);
+        unsigned long long s2 = 777;
+        for (size_t i = 0; i < big.size(); ++i) { unsigned lo = rb(s2), hi = rb(s2); big[i] = lo | (hi << 16); }
+        for (size_t off = 0; off + big.size() * 4 <= tile_bytes; off += big.size() * 4) hipMemcpy((char*)tiles + off, big.data(), big.size() * 4, hipMemcpyHostToDevice);
+    }
+#endif
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int blocks = LAB_OCC == 1 ? 1024 : 2048;
