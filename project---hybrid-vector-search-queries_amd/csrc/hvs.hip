@@ -462,7 +462,8 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     if (nq2 && (rc = run_batch_exact(c, 0, nq2, sn, B.qid + slot2, false))) return rc;
     if (slot_begin >= slot_end) return HVS_OK;
     const uint32_t waves = (slot_end - slot_begin + 63u) / 64u;
-    const uint32_t nchunks = std::max(1u, std::min(64u, (8192u + waves - 1u) / waves));
+    uint32_t nchunks = std::max(1u, std::min(64u, (8192u + waves - 1u) / waves));
+    nchunks = std::min(nchunks, std::max(1u, (1u << 20) / B.nslots));  // candidate lists: at most 2 GB
     const size_t lists = (size_t)B.nslots * nchunks;
     if (lists > c->cand_lists) {
         if ((rc = dev_alloc(c, &c->d_cand, lists * HVS_CAND_CAP))) return rc;
