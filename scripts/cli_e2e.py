@@ -1,0 +1,20 @@
+"""End-to-end run of the reference-compatible driver (hvs_search.out) on generated files: PCIe-inclusive
+wall time of the vec_query-equivalent region (host rows in -> ids out), as the reference times it."""
+import importlib, os, subprocess, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import hvs_testlib as T
+PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
+n, nq = int(sys.argv[1]), int(sys.argv[2])
+with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+    d, q, o = os.path.join(tmp, "d.bin"), os.path.join(tmp, "q.bin"), os.path.join(tmp, "o.bin")
+    nodes = T.gen_data(n); queries = T.gen_queries(nq)
+    T.write_bin(d, nodes); T.write_bin(q, queries)
+    t0 = time.time()
+    r = subprocess.run([PKG.cli_path(), d, q, o], capture_output=True, text=True)
+    wall = time.time() - t0
+    print([l for l in r.stderr.splitlines() if "Vector Search took" in l], f"process wall {wall:.2f} s")
+    ids = T.read_knn(o)
+    sel = np.arange(0, nq, max(1, nq // 64))
+    ref, _ = T.oracle_query(nodes, queries[sel], threads=16)
+    print(T.check_parity(nodes, queries[sel], ids[sel], ref))
