@@ -81,3 +81,30 @@ def test_data_sharded_merge_matches_the_whole_set_answer():
     want, want_d = T.oracle_query(nodes, queries)
     assert np.array_equal(ids, want) and np.array_equal(dists.view(np.uint32), want_d.view(np.uint32))
     assert any(int(T._passes(nodes, q).sum()) < 100 for q in queries), "the case must exercise padding"
+
+
+def _worker_rows(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, nq = 1500, 40
+    nodes, queries = T.gen_data(n, 21, T.GEN_V1, 30), T.gen_queries(nq, 22, T.GEN_V1, 30)
+    r0, r1 = sharding.row_shard_range(n, rank, world)
+    tail = np.arange(n - 1, n - 101, -1, dtype=np.uint32)
+    pad = T.oracle_dists_for_ids(nodes, queries, np.tile(tail, (nq, 1)))   # same on every rank
+    ids, dists = sharding.run_data_sharded(lambda q: _brute_partial(nodes, q, r0, r1), r0, n, queries, pad)
+    np.save(os.path.join(out_dir, f"rows{rank}.npy"), ids)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_sharded_run(tmp_path):
+    """D-sharded plan end to end over gloo: each rank answers all queries on half of the rows, partial
+    lists are all-gathered and merged on every rank."""
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_rows, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    nodes, queries = T.gen_data(1500, 21, T.GEN_V1, 30), T.gen_queries(40, 22, T.GEN_V1, 30)
+    want, _ = T.oracle_query(nodes, queries)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rows{r}.npy"), want)
