@@ -116,11 +116,15 @@ def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None
     ids_t = torch.from_numpy(np.ascontiguousarray(ids, np.uint32).view(np.int32)).to(device)
     d_t = torch.from_numpy(np.ascontiguousarray(dists, np.float32)).to(device)
     r0_t = torch.tensor([row0], dtype=torch.int64, device=device)
-    ids_all = torch.empty((world,) + tuple(ids_t.shape), dtype=ids_t.dtype, device=device)
-    d_all = torch.empty((world,) + tuple(d_t.shape), dtype=d_t.dtype, device=device)
+    nq = ids_t.shape[0]
+    # concatenated (not stacked) outputs: the layout every backend's all_gather_into_tensor accepts
+    ids_all = torch.empty((world * nq, ids_t.shape[1]), dtype=ids_t.dtype, device=device)
+    d_all = torch.empty((world * nq, d_t.shape[1]), dtype=d_t.dtype, device=device)
     r0_all = torch.empty((world,), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(ids_all, ids_t, group=group)
     dist.all_gather_into_tensor(d_all, d_t, group=group)
     dist.all_gather_into_tensor(r0_all, r0_t, group=group)
+    ids_all = ids_all.view(world, nq, -1)
+    d_all = d_all.view(world, nq, -1)
     parts = [(ids_all[r].cpu().numpy().view(np.uint32), d_all[r].cpu().numpy(), int(r0_all[r])) for r in range(world)]
     return merge_data_shards(parts, n_total, pad_dists)
