@@ -702,17 +702,19 @@ __global__ void hvs_k_count_prefix_pairs(HvsBatch B, const uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 // hvs_k_filter_mfma -- the dominant kernel.
 //
-// Work item = (group of 4 query blocks = 128 queries, one level, one segment of <= HVS_SEG row
-// blocks of the group's storage run).  One wave per item, 4 items (consecutive groups, same
-// segment index) per 256-thread workgroup so that waves streaming the same tiles share L1/L2.
+// Work item of a wave = (group of 4 query blocks = 128 queries, one level, one segment of <= HVS_SEG
+// row blocks of the level's storage).  A 256-thread workgroup = 4 waves = 4 consecutive groups on the
+// SAME segment: each 7 KiB tile is brought into LDS once per workgroup by LDS-DMA (stages of 4 tiles,
+// double-buffered, one barrier per stage) and read from there by all four waves.
 //
-// Per row block: 7 x global_load_dwordx4 fetch the A fragments (1 KiB per instruction, lane-linear,
-// perfectly coalesced); for each of the wave's 4 resident query blocks a chain of 7
-// v_mfma_f32_32x32x16_bf16 yields  s[row][query] = q.d - |d|^2/2 ; the 16 accumulators of a lane
-// belong to ONE query (the lane's column), so the test "could this row still enter the query's
-// top-100"  s >= theta[query]  needs one v_max3 tree and one compare against a per-lane constant.
-// Rare survivors are range-checked, packed as (slot << 32 | position) into a wave-private LDS
-// buffer and flushed to the group's pair list with one returning atomic per ~200 pairs.
+// Per tile and wave: 7 x ds_read_b128 fetch the A fragments; against each of the wave's 4 resident
+// query blocks (B fragments in 112 VGPRs) a chain of 7 v_mfma_f32_32x32x16_bf16 yields
+// s[row][query] = q.d - |d|^2/2; the four chains are interleaved k-step by k-step.  The 16
+// accumulators of a lane belong to ONE query (the lane's column), so the test "could this row still
+// enter the query's top-100"  s >= theta[query]  needs one v_max3 tree and one compare against a
+// per-lane constant.  Rare survivors are found by a v_cmp + scalar-branch scan of the 16 accumulators,
+// range-checked, packed as (slot << 32 | position) into a wave-private LDS buffer and flushed to the
+// group's pair list with one returning atomic per ~200 pairs.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ hvs_bf16x8 hvs_as_bf16x8(const uint4& u)
 {
