@@ -892,6 +892,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                 // v_max3 trees of one query block overlap the MFMAs of the next
                 hvs_f32x16 acc[HVS_QB];
                 bool hit[HVS_QB];
+                float gm[HVS_QB][4];
     #pragma unroll
                 for (int qb = 0; qb < HVS_QB; ++qb) {
                     acc[qb] = hvs_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -902,12 +903,14 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                 bool anyhit = false;
     #pragma unroll
                 for (int qb = 0; qb < HVS_QB; ++qb) {
-                    float m = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), acc[qb][2]);
+                    // maxima of the four groups of 4 accumulators (4 consecutive rows each) are kept: the
+                    // survivor scan first finds the group, then looks at its 4 accumulators only
     #pragma unroll
-                    for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[qb][r]), acc[qb][r + 1]);
-                    m = fmaxf(m, acc[qb][15]);
+                    for (int k = 0; k < 4; ++k)
+                        gm[qb][k] = fmaxf(fmaxf(fmaxf(acc[qb][4 * k], acc[qb][4 * k + 1]), acc[qb][4 * k + 2]), acc[qb][4 * k + 3]);
+                    const float m = fmaxf(fmaxf(fmaxf(gm[qb][0], gm[qb][1]), gm[qb][2]), gm[qb][3]);
                     // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
-                hit[qb] = (m >= theta[qb]) & (bp * 32u + 32u > ra[qb]) & (bp * 32u < rb[qb]);
+                    hit[qb] = (m >= theta[qb]) & (bp * 32u + 32u > ra[qb]) & (bp * 32u < rb[qb]);
     #ifdef HVS_EXPERIMENT_NOHIT
                     hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
     #endif
@@ -924,18 +927,24 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                         if (__ballot(hit[qb]) == 0ull) continue;
                         const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
     #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
-                            // and the append only run for the rare accumulator that beats the threshold
-                            const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
-                            if (m0 != 0ull) {
-                                const uint32_t pos = bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                                const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
-                                const uint64_t mask = __ballot(c);
-                                if (mask != 0ull) {
-                                    if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
-                                    wcnt += (uint32_t)__popcll(mask);
-                                    if (wcnt > 192u) flush();
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            if (__ballot(gm[qb][k4] >= theta[qb]) == 0ull) continue;  // nothing in this group of 4
+    #pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int r = 4 * k4 + rr;
+                                // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
+                                // and the append only run for the rare accumulator that beats the threshold
+                                const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
+                                if (m0 != 0ull) {
+                                    const uint32_t pos =
+                                        bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+                                    const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
+                                    const uint64_t mask = __ballot(c);
+                                    if (mask != 0ull) {
+                                        if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
+                                        wcnt += (uint32_t)__popcll(mask);
+                                        if (wcnt > 192u) flush();
+                                    }
                                 }
                             }
                         }
