@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
 BF16_PEAK_TFLOPS = 2500.0  # dense BF16 MFMA peak
+INT8_PEAK_TOPS = 5000.0    # dense INT8 MFMA peak (2x BF16 per clock)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -131,7 +132,7 @@ def main():
         value = nq_total / elapsed
         flops_alg = 200.0 * pairs                                      # 2*100 per passing pair
         k_s = kern_ms / 1e3
-        peak = BF16_PEAK_TFLOPS if engine_id == 2 else FP32_PEAK_TFLOPS
+        peak = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
         achieved = flops_alg / k_s / 1e12 if k_s > 0 else 0.0
         traffic = None
         tf = os.path.join(REPO, "profiles", "traffic.json")
@@ -154,15 +155,16 @@ def main():
                        "sharding": "Q partitioned across ranks, D replicated, RCCL all_gather of ids"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": "hvs_k_scan_exact" if engine_id != 2 else "hvs_k_filter_mfma",
+                         "kernel": {2: "hvs_k_filter_mfma<bf16>", 3: "hvs_k_filter_mfma<int8>"}.get(engine_id, "hvs_k_scan_exact"),
+                         "peak_is": {2: "dense BF16 MFMA", 3: "dense INT8 MFMA (integer ops)"}.get(engine_id, "FP32 vector"),
                          "kernel_ms_avg": kern_ms / max(kern_launches, 1), "launches": kern_launches,
                          "pairs_per_launch": pairs / max(kern_launches, 1),
                          "evaluated_pairs_per_launch": scanned / max(kern_launches, 1),
                          "device_query_ms_per_step": query_ms / a.steps,
                          "rescored_pairs_per_query": rescored / max(a.batch * a.steps, 1),
                          # context, not the peak: a bare loop of the same MFMA chains sustains this much on random
-                         # BF16 operands on this chip (DVFS; scripts/mfma_loop_lab.hip -DLAB_RANDOM)
-                         "measured_mfma_ceiling_random_operands_tflops": 1592.0 if engine_id == 2 else None,
+                         # operands on this chip (DVFS; scripts/mfma_loop_lab.hip / mfma_i8_lab.hip -DLAB_RANDOM)
+                         "measured_mfma_ceiling_random_operands_tflops": {2: 1592.0, 3: 3444.0}.get(engine_id),
                          "fallback_queries": fallback},
             "load_s": load_s,
         }

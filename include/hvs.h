@@ -40,6 +40,8 @@ typedef struct hvs_ctx hvs_ctx;
 #define HVS_ENGINE_AUTO 0
 #define HVS_ENGINE_EXACT_SCAN 1 /* FP32 exact-order scan of every candidate row (VALU)       */
 #define HVS_ENGINE_MFMA_FILTER 2 /* BF16 MFMA bound filter + exact-order re-scoring (same answers) */
+#define HVS_ENGINE_MFMA_I8 3     /* INT8 MFMA bound filter + exact-order re-scoring (same answers); falls back to
+                                    the BF16 filter for data the INT8 format cannot bound */
 
 typedef struct hvs_timing {
     double query_ms;      /* whole vec_query-equivalent region on the device stream (HIP events)   */

@@ -60,9 +60,14 @@ struct hvs_ctx {
     HvsLevels lv{};                       // same block count for both orderings
     uint64_t *d_keys_ct = nullptr, *d_keys_t = nullptr;   // sorted attribute keys
     uint32_t *d_perm_ct = nullptr, *d_perm_t = nullptr;   // position -> original row id
-    uint4 *d_tiles_ct = nullptr, *d_tiles_t = nullptr;    // BF16 A-operand tiles, level-interleaved
+    uint4 *d_tiles_ct = nullptr, *d_tiles_t = nullptr;    // A-operand tiles (BF16 or INT8), level-interleaved
+    uint4 *d_nrm_ct = nullptr, *d_nrm_t = nullptr;        // INT8 format: the rows' accumulator inits, [nblk][32] int32
     uint32_t *d_bpos_ct = nullptr, *d_bpos_t = nullptr;   // storage index -> block
     HvsBounds* d_bounds = nullptr;
+    HvsQuant* d_quant = nullptr;                          // INT8 format: centre and scale
+    int tile_fmt = HVS_FMT_NONE;                          // format of the tiles currently built
+    int planned_fmt = HVS_FMT_BF16;                       // what HVS_ENGINE_AUTO uses for this data set
+    bool i8_usable = false;
     double index_ms = 0.0;
     // ... and per-batch state
     HvsBatch fb{};
@@ -260,14 +265,125 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
 // ---------------------------------------------------------------------------------------------
 void free_index(hvs_ctx* c)
 {
-    void* ptrs[] = {c->d_keys_ct, c->d_keys_t, c->d_perm_ct, c->d_perm_t, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t};
+    void* ptrs[] = {c->d_keys_ct, c->d_keys_t, c->d_perm_ct, c->d_perm_t, c->d_tiles_ct, c->d_tiles_t,
+                    c->d_nrm_ct,  c->d_nrm_t,  c->d_bpos_ct, c->d_bpos_t};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_keys_ct = c->d_keys_t = nullptr;
     c->d_perm_ct = c->d_perm_t = nullptr;
     c->d_tiles_ct = c->d_tiles_t = nullptr;
+    c->d_nrm_ct = c->d_nrm_t = nullptr;
     c->d_bpos_ct = c->d_bpos_t = nullptr;
     c->have_index = false;
+    c->tile_fmt = HVS_FMT_NONE;
+    c->i8_usable = false;
+}
+
+// Planner of HVS_ENGINE_AUTO: which tile format filters this data set more cheaply.  The INT8 filter does
+// 4 matrix instructions per tile instead of 7 at the same instruction rate (measured 1.8-1.9x the tile rate,
+// scripts/mfma_i8_lab.hip) but its error band can be wider, which inflates the number of survivors the exact
+// kernel re-scores by about exp(z * 2 band / sigma): sigma = spread of squared distances between rows,
+// z = how many sigmas below the mean the 100th neighbour of n rows sits.  Everything here is an estimate
+// from a sample of rows -- it decides speed only, both formats give the same answers.
+int choose_format(hvs_ctx* c)
+{
+    const uint32_t n = c->n;
+    c->planned_fmt = HVS_FMT_BF16;
+    c->i8_usable = false;
+    if (!c->d_quant) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_quant), sizeof(HvsQuant)));
+    hipLaunchKernelGGL(hvs_k_quant_reset, dim3(1), dim3(128), 0, c->stream, c->d_quant);
+    hipLaunchKernelGGL(hvs_k_minmax, dim3(std::min(n, 4096u)), dim3(128), 0, c->stream, c->d_data, n, c->d_quant);
+    hipLaunchKernelGGL(hvs_k_quant_params, dim3(1), dim3(128), 0, c->stream, c->d_quant);
+    if (!c->d_bounds) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_bounds), sizeof(HvsBounds)));
+    HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
+    const uint32_t step = std::max(1u, n / 65536u);
+    const uint32_t samples = hvs_ceil_div(n, step);
+    hipLaunchKernelGGL(hvs_k_plan_stats, dim3(hvs_ceil_div(samples, 256u)), dim3(256), 0, c->stream, c->d_data, n, step,
+                       c->d_quant, c->d_bounds);
+    HVS_HIP(c, hipGetLastError());
+    HvsBounds hb{};
+    double sd = 0.0;
+    HVS_HIP(c, hipMemcpyAsync(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipMemcpyAsync(&sd, reinterpret_cast<const char*>(c->d_quant) + offsetof(HvsQuant, sd), sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->i8_usable = sd > 0.0 && std::isfinite(sd);
+    if (!c->i8_usable || hb.pair_n < 16u) return HVS_OK;
+    const double mean = hb.pair_sum / hb.pair_n;
+    const double var = hb.pair_sumsq / hb.pair_n - mean * mean;
+    const double sigma = std::sqrt(std::max(var, 1e-300));
+    // z of the 100th neighbour among n rows (normal tail, crude): 100/n = Phi(-z)
+    const double pq = std::min(0.4, 100.0 / (double)n);
+    const double z = std::sqrt(std::max(0.0, -2.0 * std::log(pq) - std::log(-2.0 * std::log(pq) * 6.2832)));
+    // bands for a query that looks like a row (|q| ~ row norm, quantisation error ~ row error)
+    const double band16 = 2.0 * (double)hb.nb_d * (double)hb.e_d + 4.0e-5 * ((double)hb.nb_d * (double)hb.nb_d + (double)hb.hmax);
+    const double band8 = 2.0 * (double)hb.n_d8 * (double)hb.e_d8;
+    const double infl16 = std::exp(std::min(50.0, z * 2.0 * band16 / sigma));
+    const double infl8 = std::exp(std::min(50.0, z * 2.0 * band8 / sigma));
+    // cost model (D = 1e7 mixed batch, profiles/): BF16 filter 188 + re-scoring 38 ms per step at inflation ~1;
+    // INT8 filter ~100 ms
+    const double cost16 = 188.0 + 38.0 * infl16, cost8 = 100.0 + 38.0 * infl8;
+    c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? HVS_FMT_I8 : HVS_FMT_BF16;
+    if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "i8"
+        if (!std::strcmp(f, "bf16")) c->planned_fmt = HVS_FMT_BF16;
+        if (!std::strcmp(f, "i8")) c->planned_fmt = HVS_FMT_I8;
+    }
+    return HVS_OK;
+}
+
+// (re)build the level-interleaved tiles of both orderings in format `fmt`; the orderings must exist
+int build_tiles(hvs_ctx* c, int fmt)
+{
+    const HvsLevels L = c->lv;
+    const uint32_t n = c->n;
+    int rc;
+    c->tile_fmt = HVS_FMT_NONE;
+    c->have_index = false;
+    // free first: the two formats never coexist (D = 1e8: 44.8 GB of BF16 tiles, 26.4 GB of INT8 tiles)
+    if ((rc = dev_alloc(c, &c->d_tiles_ct, (size_t)0))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tiles_t, (size_t)0))) return rc;
+    if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)0))) return rc;
+    if ((rc = dev_alloc(c, &c->d_nrm_t, (size_t)0))) return rc;
+    const size_t tile_u4 = fmt == HVS_FMT_I8 ? HVS_I8_TILE_U4 : HVS_TILE_U4;
+    if ((rc = dev_alloc(c, &c->d_tiles_ct, (size_t)L.nblk * tile_u4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tiles_t, (size_t)L.nblk * tile_u4))) return rc;
+    if (fmt == HVS_FMT_I8) {
+        if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)L.nblk * HVS_I8_NRM_U4))) return rc;
+        if ((rc = dev_alloc(c, &c->d_nrm_t, (size_t)L.nblk * HVS_I8_NRM_U4))) return rc;
+    }
+    if (!c->d_bpos_ct && (rc = dev_alloc(c, &c->d_bpos_ct, (size_t)L.nblk))) return rc;
+    if (!c->d_bpos_t && (rc = dev_alloc(c, &c->d_bpos_t, (size_t)L.nblk))) return rc;
+    HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
+    const dim3 grid((L.nblk + 3u) / 4u);
+    if (fmt == HVS_FMT_I8) {
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_quant,
+                           c->d_tiles_ct, reinterpret_cast<int*>(c->d_nrm_ct), c->d_bpos_ct, c->d_bounds);
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_quant,
+                           c->d_tiles_t, reinterpret_cast<int*>(c->d_nrm_t), c->d_bpos_t, c->d_bounds);
+    } else {
+        hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_tiles_ct,
+                           c->d_bpos_ct, c->d_bounds);
+        hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_tiles_t,
+                           c->d_bpos_t, c->d_bounds);
+    }
+    HVS_HIP(c, hipGetLastError());
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    // the error bound needs finite row norms: data with inf/NaN components (or |d|^2 overflowing f32)
+    // is answered by the exact engine only
+    HvsBounds hb{};
+    HVS_HIP(c, hipMemcpy(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost));
+    bool ok;
+    if (fmt == HVS_FMT_I8)
+        ok = std::isfinite(hb.e_d8) && std::isfinite(hb.n_d8) && hb.n_d8 < 1.0e15f;
+    else
+        // (norms near the f32 denormal range: BF16 operands might be flushed by the matrix pipe, which the
+        // error bound does not model)
+        ok = std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho) &&
+             !(hb.hmax > 1.0e30f) && !(hb.hmax > 0.0f && hb.hmax < 1.0e-20f);
+    if (!ok) return HVS_OK;  // have_index stays false
+    c->tile_fmt = fmt;
+    c->have_index = true;
+    return HVS_OK;
 }
 
 int build_index(hvs_ctx* c)
@@ -324,32 +440,23 @@ int build_index(hvs_ctx* c)
     k_ct = k_t = nullptr;
     ids = nullptr;
     tmp = nullptr;
-    HVS_TRY(dev_alloc(c, &c->d_tiles_ct, (size_t)L.nblk * HVS_TILE_U4));
-    HVS_TRY(dev_alloc(c, &c->d_tiles_t, (size_t)L.nblk * HVS_TILE_U4));
-    HVS_TRY(dev_alloc(c, &c->d_bpos_ct, (size_t)L.nblk));
-    HVS_TRY(dev_alloc(c, &c->d_bpos_t, (size_t)L.nblk));
 #undef HVS_TRY
-    if (!c->d_bounds) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_bounds), sizeof(HvsBounds)));
-    HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
-    const dim3 grid((L.nblk + 3u) / 4u);
-    hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_tiles_ct,
-                       c->d_bpos_ct, c->d_bounds);
-    hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_tiles_t,
-                       c->d_bpos_t, c->d_bounds);
-    HVS_HIP(c, hipGetLastError());
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    // the error bound needs finite row norms: data with inf/NaN components (or |d|^2 overflowing f32)
-    // is answered by the exact engine only
-    HvsBounds hb{};
-    HVS_HIP(c, hipMemcpy(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost));
-    if (!(std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho)) ||
-        hb.hmax > 1.0e30f || (hb.hmax > 0.0f && hb.hmax < 1.0e-20f)) {
-        // (norms near the f32 denormal range: BF16 operands might be flushed by the matrix pipe, which the
-        // error bound does not model)
+    if ((rc = choose_format(c))) {
         free_index(c);
-        return HVS_OK;
+        return rc;
     }
-    c->have_index = true;
+    int fmt = c->planned_fmt;
+    if (c->engine == HVS_ENGINE_MFMA_FILTER) fmt = HVS_FMT_BF16;
+    if (c->engine == HVS_ENGINE_MFMA_I8 && c->i8_usable) fmt = HVS_FMT_I8;
+    if ((rc = build_tiles(c, fmt))) {
+        free_index(c);
+        return rc;
+    }
+    if (!c->have_index && fmt == HVS_FMT_I8 && (rc = build_tiles(c, HVS_FMT_BF16))) {
+        free_index(c);
+        return rc;
+    }
+    if (!c->have_index) free_index(c);  // neither format has a usable bound: exact engine only
     return HVS_OK;
 }
 
@@ -374,6 +481,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
         HVS_A(gord, groups);
         HVS_A(bfrag, (size_t)(slots / 32u) * HVS_TILE_U4);
         HVS_A(theta, slots);
+        B.thetai = reinterpret_cast<int*>(B.theta);
         HVS_A(qn, slots);
         HVS_A(normq, slots);
         HVS_A(eq, slots);
@@ -404,7 +512,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
 
 // slot layout, position ranges, norms and B fragments of one batch (shared by the MFMA engine and the
 // range-based exact engine)
-int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs)
+int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt)
 {
     int rc = ensure_filter_workspace(c, nqb);
     if (rc) return rc;
@@ -431,8 +539,8 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs)
     hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, B.qid,
                        B.rank, c->d_layout);
     hipLaunchKernelGGL(hvs_k_prep_slots, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, B, c->d_keys_ct,
-                       c->d_keys_t, n, count_pairs ? 1 : 0, c->d_counters);
-    hipLaunchKernelGGL(hvs_k_prep_groups, dim3(B.ngroups), dim3(HVS_GROUP), 0, c->stream, c->d_q, B);
+                       c->d_keys_t, n, count_pairs ? 1 : 0, c->d_counters, fmt, c->d_quant);
+    hipLaunchKernelGGL(hvs_k_prep_groups, dim3(B.ngroups), dim3(HVS_GROUP), 0, c->stream, c->d_q, B, fmt, c->d_quant);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -445,7 +553,7 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs)
 // streaming all of them (8.2 k vs 14 k queries/s).
 int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 {
-    int rc = prep_batch(c, q0, nqb, sn == c->n);
+    int rc = prep_batch(c, q0, nqb, sn == c->n, HVS_FMT_BF16);  // (the range scan uses the ranges only)
     if (rc) return rc;
     HvsBatch& B = c->fb;
     if (sn != c->n)
@@ -499,7 +607,8 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 
 int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 {
-    int rc = prep_batch(c, q0, nqb, sn == c->n);
+    const int fmt = c->tile_fmt;
+    int rc = prep_batch(c, q0, nqb, sn == c->n, fmt);
     if (rc) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
@@ -511,7 +620,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, sn, c->d_q, B,
                        c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                       c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
+                       c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
     // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on
     // D=1e6 x 1e4 queries: fewer launches but 3x the candidates per round -- slower, 0.93 vs 1.01 M q/s.)
     const uint32_t lstep = 1u;
@@ -522,9 +631,13 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
             const uint32_t count = L.off[level + 1] - L.off[level];
             const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
             if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
-            hipLaunchKernelGGL(hvs_k_filter_mfma, dim3(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG)),
-                               dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t, c->d_bpos_ct, c->d_bpos_t, L,
-                               level, B, c->d_counters);
+            const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
+            if (fmt == HVS_FMT_I8)
+                hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_I8>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
+                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
+            else
+                hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_BF16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
+                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
             if (ev >= 0) {
                 HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
                 c->n_launch_events++;
@@ -533,7 +646,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
         hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                           c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
+                           c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
     }
     // queries whose candidate lists overflowed are answered again by the exact engine
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
@@ -563,7 +676,21 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     // exact stages drop them, so its candidate lists grow by n/sn -- used down to sn = n/4, below that
     // the exact engine answers.
     bool mfma = c->have_index && sn >= c->n / 4u && sn > 0u && !c->scalar_order &&
-                (c->engine == HVS_ENGINE_MFMA_FILTER || (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
+                (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
+                 (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
+    if (mfma) {
+        // the tiles exist in one format at a time: an engine choice made after the load rebuilds them
+        int want = c->engine == HVS_ENGINE_MFMA_FILTER ? HVS_FMT_BF16
+                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable ? HVS_FMT_I8 : HVS_FMT_BF16)
+                                                       : c->planned_fmt;
+        if (want != c->tile_fmt) {
+            const int had = c->tile_fmt;
+            int rc = build_tiles(c, want);
+            if (rc) return rc;
+            if (!c->have_index && (rc = build_tiles(c, had))) return rc;  // no usable bound in that format
+            if (!c->have_index) return fail(c, HVS_ESTATE, "internal: tile rebuild lost the index");
+        }
+    }
     c->timing_valid = false;
     c->n_launch_events = 0;
     c->fallback_queries = 0;
@@ -580,7 +707,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     c->timing = hvs_timing{};
     c->timing.nq = nq;
-    c->timing.engine = mfma ? HVS_ENGINE_MFMA_FILTER : HVS_ENGINE_EXACT_SCAN;
+    c->timing.engine = mfma ? (c->tile_fmt == HVS_FMT_I8 ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
     c->timing.fallback_queries = c->fallback_queries;
     c->timing_valid = true;
@@ -678,10 +805,12 @@ const char* hvs_last_error(const hvs_ctx* c) { return c ? c->err.c_str() : "hvs:
 int hvs_set_engine(hvs_ctx* c, int engine)
 {
     if (!c) return HVS_EINVAL;
-    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER)
+    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER &&
+        engine != HVS_ENGINE_MFMA_I8)
         return fail(c, HVS_EINVAL, "hvs_set_engine: unknown engine");
     c->engine = engine;
-    if (c->d_data && !c->have_index && (engine == HVS_ENGINE_MFMA_FILTER || c->n >= kIndexMinRows)) {
+    if (c->d_data && !c->have_index &&
+        (engine == HVS_ENGINE_MFMA_FILTER || engine == HVS_ENGINE_MFMA_I8 || c->n >= kIndexMinRows)) {
         HVS_HIP(c, hipSetDevice(c->device));
         return build_index(c);
     }
@@ -724,7 +853,7 @@ static int finish_data(hvs_ctx* c)
     c->load_ms = ms;
     free_index(c);
     // the index (two orderings + BF16 tiles) serves both engines: the exact engine scans position ranges
-    if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER) return HVS_OK;
+    if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER && c->engine != HVS_ENGINE_MFMA_I8) return HVS_OK;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     int rc = build_index(c);
     if (rc == HVS_ENOMEM) {

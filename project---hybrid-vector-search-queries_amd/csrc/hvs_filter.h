@@ -58,6 +58,17 @@
 
 typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float hvs_f32x16 __attribute__((ext_vector_type(16)));
+typedef int hvs_i32x4 __attribute__((ext_vector_type(4)));
+typedef int hvs_i32x16 __attribute__((ext_vector_type(16)));
+
+// Tile formats of the filter (see "INT8 filter" below).  The level/slot machinery is shared.
+#define HVS_FMT_NONE 0
+#define HVS_FMT_BF16 1
+#define HVS_FMT_I8 2
+#define HVS_I8_KSTEPS 4        // 4 k-steps of 32 (K padded 100 -> 128)
+#define HVS_I8_TILE_U4 (HVS_I8_KSTEPS * 64)  // uint4 per 32-row INT8 tile (4 KiB)
+#define HVS_I8_NRM_U4 8        // uint4 per tile of per-row accumulator inits (32 x int32)
+#define HVS_I8_PAD_NORM (-(1 << 30))  // accumulator init of a padding row: can never reach a threshold
 
 // ---------------------------------------------------------------------------------------------
 // order-preserving integer keys of f32 attributes.  -0 is folded into +0 (they compare equal in
@@ -195,7 +206,195 @@ struct HvsBounds {  // global maxima over rows, all rounded up
     float nb_d;   // max |bf16(d)|_2
     float hmax;   // max |d|^2 / 2
     float rho;    // max | |d|^2/2 + (h0+h1+h2) |
+    // INT8 format (d' = d - center, dq = int8 image of d'):
+    float e_d8;   // max |d' - sd dq|_2
+    float n_d8;   // max |d'|_2
+    // planner sample: sum and sum of squares of |a-b|^2 over sampled pairs of rows, and their number
+    double pair_sum, pair_sumsq;
+    uint32_t pair_n;
 };
+
+// ---------------------------------------------------------------------------------------------
+// INT8 filter.  Distances are translation invariant, so rows and queries are taken relative to a
+// per-dimension centre c (midrange of D):  d' = d - c, q' = q - c, and quantised with ONE scale sd for
+// rows and queries alike:  dq = clamp(rint(d'/sd), +-127) (no row is clipped: sd = max |d'_k| / 127),
+// qq likewise (queries outside D's bounding box are clipped; their error e_q then carries it).
+//   q'.d' = sd^2 qq.dq + (sd qq).(d' - sd dq) + (q' - sd qq).d'
+//   s := q'.d' - |d'|^2/2  <=  sd^2 (qq.dq + nh + 1) + |sd qq| E_D + e_q N_D,   nh = floor(-|d'|^2 / (2 sd^2))
+// v_mfma_i32_32x32x32_i8 started from the accumulator init nh yields S = qq.dq + nh EXACTLY (no
+// accumulation error term), so a row is discarded iff  S < theta_i := floor((|q'|^2 - tau(1+2g))/(2 sd^2)
+// - band/sd^2) - 2  with band = |sd qq| E_D + e_q N_D  (hvs_k_merge).  For data that fills its bounding
+// box evenly the band is about the BF16 one (BF16 of uncentred data pays |q| ~ 2x |q'|); heavy-tailed
+// data widens it, which only costs re-scoring work, never correctness -- the planner (hvs.hip,
+// choose_format) estimates that cost from a sample of row pairs.
+// ---------------------------------------------------------------------------------------------
+struct HvsQuant {
+    float center[HVS_NDIM];
+    double sd;       // scale; 0 or non-finite: format unusable
+    double inv_sd;
+    uint32_t kmin[HVS_NDIM], kmax[HVS_NDIM];  // per-dimension min / max as order-preserving keys (hvs_attr_key)
+};
+
+__host__ __device__ static inline float hvs_attr_key_inv(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+__global__ void hvs_k_quant_reset(HvsQuant* __restrict__ qz)
+{
+    const uint32_t k = threadIdx.x;
+    if (k < HVS_NDIM) {
+        qz->kmin[k] = 0xFFFFFFFFu;
+        qz->kmax[k] = 0u;
+    }
+}
+
+// per-dimension min / max of the vector components; blockDim = 128 (thread = dimension), rows strided over blocks
+__global__ __launch_bounds__(128) void hvs_k_minmax(const float* __restrict__ D, uint32_t n, HvsQuant* __restrict__ qz)
+{
+    const uint32_t k = threadIdx.x;
+    if (k >= HVS_NDIM) return;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t key = hvs_attr_key(D[(size_t)i * HVS_DCOLS + 2 + k]);
+        lo = key < lo ? key : lo;
+        hi = key > hi ? key : hi;
+    }
+    atomicMin(&qz->kmin[k], lo);
+    atomicMax(&qz->kmax[k], hi);
+}
+
+__global__ void hvs_k_quant_params(HvsQuant* __restrict__ qz)
+{
+    __shared__ double half[HVS_NDIM];
+    const uint32_t k = threadIdx.x;
+    if (k < HVS_NDIM) {
+        const double lo = (double)hvs_attr_key_inv(qz->kmin[k]), hi = (double)hvs_attr_key_inv(qz->kmax[k]);  // NaN key -> NaN
+        const float c = (float)(0.5 * (lo + hi));
+        qz->center[k] = c;
+        const double a = fabs(lo - (double)c), b = fabs(hi - (double)c);
+        half[k] = (a != a || b != b) ? (double)__builtin_inff() : (a > b ? a : b);
+    }
+    __syncthreads();
+    if (k == 0u) {
+        double m = 0.0;
+        for (int i = 0; i < HVS_NDIM; ++i) m = half[i] > m ? half[i] : m;
+        // no row is clipped; all rows equal: any scale works
+        double sd = m > 0.0 ? m / 127.0 * (1.0 + 1e-9) : 1.0;
+        if (!(sd < 1.0e18) || sd < 1.0e-18) sd = 0.0;  // non-finite or extreme ranges: INT8 format unusable
+        qz->sd = sd;
+        qz->inv_sd = sd > 0.0 ? 1.0 / sd : 0.0;
+    }
+}
+
+__device__ __forceinline__ int hvs_quant_i8(double x, double inv_sd)
+{
+    double r = rint(x * inv_sd);
+    r = r > 127.0 ? 127.0 : (r < -127.0 ? -127.0 : r);
+    return (r == r) ? (int)r : 0;
+}
+
+// one wave per storage block: 4 KiB INT8 A-operand tile (lane l of k-step s: row l&31, k = 32 s + 16 (l>>5) + 0..15),
+// the 32 accumulator inits and the row bounds
+__global__ __launch_bounds__(256) void hvs_k_build_tiles_i8(const float* __restrict__ D, uint32_t n,
+                                                            const uint32_t* __restrict__ perm, HvsLevels L,
+                                                            const HvsQuant* __restrict__ qz, uint4* __restrict__ tiles,
+                                                            int* __restrict__ norms, uint32_t* __restrict__ blockpos,
+                                                            HvsBounds* __restrict__ bounds)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= L.nblk) return;
+    const uint32_t b = hvs_storage_to_block(L, idx);
+    if (lane == 0u) blockpos[idx] = b;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t pos = b * 32u + r;
+    const bool valid = pos < n;
+    const float* __restrict__ row = D + (size_t)(valid ? perm[pos] : 0u) * HVS_DCOLS + 2;
+    const double sd = qz->sd, inv_sd = qz->inv_sd;
+    if (h == 0u) {
+        double nd = 0.0, e2 = 0.0;
+        for (int k = 0; k < HVS_NDIM; ++k) {
+            const double x = (double)row[k] - (double)qz->center[k];
+            const double xq = sd * (double)hvs_quant_i8(x, inv_sd);
+            nd += x * x;
+            e2 += (x - xq) * (x - xq);
+        }
+        int nh = HVS_I8_PAD_NORM;
+        if (valid) {
+            const double v = floor(-0.5 * nd * inv_sd * inv_sd);
+            nh = v > -1.0e9 ? (int)v : HVS_I8_PAD_NORM;  // (|d'_k| <= 127 sd: v >= -806450)
+            hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30));
+            hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd) * (1.0 + 1e-9) + 1e-30));
+        }
+        norms[(size_t)idx * 32u + r] = nh;
+    }
+#pragma unroll
+    for (int s = 0; s < HVS_I8_KSTEPS; ++s) {
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 32 * s + 16 * (int)h + 4 * p + e;
+                int v = 0;
+                if (valid && k < HVS_NDIM) v = hvs_quant_i8((double)row[k] - (double)qz->center[k], inv_sd);
+                word |= ((uint32_t)v & 0xFFu) << (8 * e);
+            }
+            w[p] = word;
+        }
+        tiles[((size_t)idx * HVS_I8_KSTEPS + s) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Planner inputs in one pass over a sample of rows (stride `step`): the bounds BOTH formats would get
+// (from the sampled rows only -- estimates, the formats' own build kernels compute the real maxima) and
+// the spread of squared distances between sampled row pairs.  One lane per sampled row.
+__global__ void hvs_k_plan_stats(const float* __restrict__ D, uint32_t n, uint32_t step, const HvsQuant* __restrict__ qz,
+                                 HvsBounds* __restrict__ bounds)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i64 = (uint64_t)t * step;
+    if (i64 >= n) return;
+    const uint32_t i = (uint32_t)i64;
+    const uint32_t j = (uint32_t)(((uint64_t)i * 2654435761ull + 40503ull) % n);
+    const float* __restrict__ a = D + (size_t)i * HVS_DCOLS + 2;
+    const float* __restrict__ bb = D + (size_t)j * HVS_DCOLS + 2;
+    const double sd = qz->sd, inv_sd = qz->inv_sd;
+    double nd = 0.0, e2 = 0.0, nb2 = 0.0, nd8 = 0.0, e28 = 0.0, dist = 0.0;
+    for (int k = 0; k < HVS_NDIM; ++k) {
+        const float x = a[k];
+        const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+        nd += (double)x * (double)x;
+        e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
+        nb2 += (double)xb * (double)xb;
+        const double x8 = (double)x - (double)qz->center[k];
+        const double xq = sd * (double)hvs_quant_i8(x8, inv_sd);
+        nd8 += x8 * x8;
+        e28 += (x8 - xq) * (x8 - xq);
+        const double df = (double)x - (double)bb[k];
+        dist += df * df;
+    }
+    if (!(nd < 1.0e30)) return;
+    hvs_atomic_max_pos(&bounds->e_d, hvs_round_up_f32(sqrt(e2)));
+    hvs_atomic_max_pos(&bounds->nb_d, hvs_round_up_f32(sqrt(nb2)));
+    hvs_atomic_max_pos(&bounds->hmax, hvs_round_up_f32(0.5 * nd));
+    hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e28)));
+    hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd8)));
+    if (i != j && dist < 1.0e30) {
+        atomicAdd(&bounds->pair_sum, dist);
+        atomicAdd(&bounds->pair_sumsq, dist * dist);
+        atomicAdd(&bounds->pair_n, 1u);
+    }
+}
 
 // one wave per storage block: builds the 7 KiB A-operand tile and the row bounds
 __global__ __launch_bounds__(256) void hvs_k_build_tiles(const float* __restrict__ D, uint32_t n,
@@ -281,8 +480,9 @@ struct HvsBatch {
     uint32_t* gub;
     uint32_t* gord;             // [ngroups] ordering used by the group: 0 = (C,T), 1 = T
     // filter operands
-    uint4* bfrag;               // [nslots/32][7][64] BF16 B-operand fragments
-    float* theta;               // [nslots]
+    uint4* bfrag;               // [nslots/32][7][64] BF16 B-operand fragments ([nslots/32][4][64] in the INT8 format)
+    float* theta;               // [nslots] BF16 format: discard a row when its MFMA value is < theta
+    int* thetai;                // same storage, INT8 format: integer threshold
     double* qn;                 // [nslots] |q|^2
     float* normq;               // [nslots] |q| (rounded up)
     float* eq;                  // [nslots] |q - bf16(q)| (rounded up)
@@ -417,7 +617,7 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
 // per slot: position range of the predicate, norms, bound inputs; resets the top-k state
 __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
                                  const uint64_t* __restrict__ keys_t, uint32_t n, int count_pairs,
-                                 unsigned long long* __restrict__ counters)
+                                 unsigned long long* __restrict__ counters, int fmt, const HvsQuant* __restrict__ qz)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B.nslots) return;
@@ -428,33 +628,49 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
         const HvsQParams p = hvs_parse_query(q);
         hvs_query_range(p, keys_ct, keys_t, n, a, b);
-        for (int k = 0; k < HVS_NDIM; ++k) {
-            const float x = q[4 + k];
-            const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
-            qn += (double)x * (double)x;
-            e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
-            nb2 += (double)xb * (double)xb;
+        if (fmt == HVS_FMT_I8) {
+            // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2
+            const double sd = qz->sd, inv_sd = qz->inv_sd;
+            for (int k = 0; k < HVS_NDIM; ++k) {
+                const double x = (double)q[4 + k] - (double)qz->center[k];
+                const double xq = sd * (double)hvs_quant_i8(x, inv_sd);
+                qn += x * x;
+                e2 += (x - xq) * (x - xq);
+                nb2 += xq * xq;
+            }
+        } else {
+            for (int k = 0; k < HVS_NDIM; ++k) {
+                const float x = q[4 + k];
+                const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+                qn += (double)x * (double)x;
+                e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
+                nb2 += (double)xb * (double)xb;
+            }
         }
         if (count_pairs) atomicAdd(&counters[0], (unsigned long long)(b - a));
     }
     B.ra[s] = a;
     B.rb[s] = b;
     B.qn[s] = qn;
-    B.normq[s] = hvs_round_up_f32(sqrt(qn) + 1e-30);
-    B.eq[s] = hvs_round_up_f32(sqrt(e2) + 1e-30);
-    B.nqb[s] = hvs_round_up_f32(sqrt(nb2) + 1e-30);
+    B.normq[s] = hvs_round_up_f32(sqrt(qn) * (1.0 + 1e-9) + 1e-30);
+    B.eq[s] = hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30);
+    B.nqb[s] = hvs_round_up_f32(sqrt(nb2) * (1.0 + 1e-9) + 1e-30);
     B.topcnt[s] = 0;
     B.candcnt[s] = 0;
     // a query with non-finite components has no usable bound: it is answered by the exact engine
     B.overflow[s] = (qi != 0xFFFFFFFFu && !(qn < 1.0e30)) ? 1u : 0u;
     B.tau[s] = __builtin_inff();
     // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
-    B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
+    if (fmt == HVS_FMT_I8)
+        B.thetai[s] = b > a ? (int)0x80000000 : 0x7FFFFFFF;
+    else
+        B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
 }
 
 // per group: union of the slots' ranges, ordering; per block: BF16 B-operand fragments.
 // One 128-thread block per group.
-__global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __restrict__ Q, HvsBatch B)
+__global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __restrict__ Q, HvsBatch B, int fmt,
+                                                               const HvsQuant* __restrict__ qz)
 {
     __shared__ uint32_t smin[HVS_GROUP], smax[HVS_GROUP];
     const uint32_t g = blockIdx.x, t = threadIdx.x;
@@ -477,6 +693,33 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
         B.gord[g] = B.rank[g * HVS_GROUP] == 4u ? 1u : 0u;
         B.paircnt[g] = 0;
         B.goverflow[g] = 0;
+    }
+    if (fmt == HVS_FMT_I8) {
+        // INT8 B fragments: lane l of k-step ks holds query column (l & 31), k = 32 ks + 16 (l >> 5) + 0..15
+        const double inv_sd = qz->inv_sd;
+        for (uint32_t e = t; e < HVS_QB * HVS_I8_KSTEPS * 64u; e += HVS_GROUP) {
+            const uint32_t qb = e / (HVS_I8_KSTEPS * 64u);
+            const uint32_t ks = (e / 64u) % HVS_I8_KSTEPS;
+            const uint32_t l = e & 63u;
+            const uint32_t slot = g * HVS_GROUP + qb * 32u + (l & 31u);
+            const uint32_t qi = B.qid[slot];
+            uint32_t w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int k = 32 * (int)ks + 16 * (int)(l >> 5) + 4 * p + e2;
+                    int v = 0;
+                    if (qi != 0xFFFFFFFFu && k < HVS_NDIM)
+                        v = hvs_quant_i8((double)Q[(size_t)qi * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
+                    word |= ((uint32_t)v & 0xFFu) << (8 * e2);
+                }
+                w[p] = word;
+            }
+            B.bfrag[((size_t)(g * HVS_QB + qb) * HVS_I8_KSTEPS + ks) * 64u + l] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
     }
     // B fragments: lane l of k-step ks holds query column (l & 31), k = 16 ks + 8 (l >> 5) + 0..7
     for (uint32_t e = t; e < HVS_QB * HVS_KSTEPS * 64u; e += HVS_GROUP) {
@@ -726,14 +969,63 @@ __device__ __forceinline__ hvs_bf16x8 hvs_as_bf16x8(const uint4& u)
     return c.b8;
 }
 
+__device__ __forceinline__ hvs_i32x4 hvs_as_i32x4(const uint4& u)
+{
+    union {
+        uint4 u4;
+        hvs_i32x4 i4;
+    } c;
+    c.u4 = u;
+    return c.i4;
+}
+
+// operand / accumulator types and the MFMA step of the two tile formats
+template <int FMT>
+struct HvsFmt;
+template <>
+struct HvsFmt<HVS_FMT_BF16> {
+    static constexpr int KSTEPS = HVS_KSTEPS;
+    typedef hvs_bf16x8 frag_t;
+    typedef hvs_f32x16 acc_t;
+    typedef float thr_t;
+    static __device__ __forceinline__ frag_t frag(const uint4& u) { return hvs_as_bf16x8(u); }
+    static __device__ __forceinline__ acc_t mfma(const frag_t& a, const frag_t& b, const acc_t& c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ thr_t max2(thr_t a, thr_t b) { return fmaxf(a, b); }
+};
+template <>
+struct HvsFmt<HVS_FMT_I8> {
+    static constexpr int KSTEPS = HVS_I8_KSTEPS;
+    typedef hvs_i32x4 frag_t;
+    typedef hvs_i32x16 acc_t;
+    typedef int thr_t;
+    static __device__ __forceinline__ frag_t frag(const uint4& u) { return hvs_as_i32x4(u); }
+    static __device__ __forceinline__ acc_t mfma(const frag_t& a, const frag_t& b, const acc_t& c)
+    {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ thr_t max2(thr_t a, thr_t b) { return a > b ? a : b; }
+};
+
+template <int FMT>
 __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_mfma(const uint4* __restrict__ tiles_ct,
                                                             const uint4* __restrict__ tiles_t,
+                                                            const uint4* __restrict__ nrm_ct,
+                                                            const uint4* __restrict__ nrm_t,
                                                             const uint32_t* __restrict__ bpos_ct,
                                                             const uint32_t* __restrict__ bpos_t, HvsLevels L,
                                                             uint32_t level, HvsBatch B,
                                                             unsigned long long* __restrict__ counters)
 {
-    __shared__ uint4 stile[2][HVS_STAGE * HVS_TILE_U4];  // two stages of 4 A tiles shared by the 4 waves (2 x 28 KiB)
+    typedef HvsFmt<FMT> F;
+    constexpr int KS = F::KSTEPS;
+    constexpr int TILE_U4 = KS * 64;
+    constexpr bool kI8 = FMT == HVS_FMT_I8;
+    // two stages of 4 A tiles shared by the 4 waves (BF16: 2 x 28 KiB, INT8: 2 x 16 KiB + the rows' accumulator inits)
+    __shared__ uint4 stile[2][HVS_STAGE * TILE_U4];
+    __shared__ uint4 snrm[2][kI8 ? HVS_STAGE * HVS_I8_NRM_U4 : 1];
     __shared__ uint64_t sbuf[HVS_WG_WAVES][256];         // wave-private survivor buffers
     __shared__ uint32_t srange[HVS_WG_WAVES][2];
     const uint32_t lane = threadIdx.x & 63u;
@@ -749,6 +1041,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
+    const uint4* __restrict__ nrm = ord ? nrm_t : nrm_ct;
     const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
     uint32_t i0 = 0, i1 = 0;  // this wave's tiles [i0,i1) inside the segment (empty when i0 >= i1)
     if (g < B.ngroups && B.gord[g] == ord) {
@@ -776,18 +1069,21 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     const bool active = i0 < i1;
 
     // resident query operands
-    hvs_bf16x8 bq[HVS_QB][HVS_KSTEPS];
-    float theta[HVS_QB];
+    typename F::frag_t bq[HVS_QB][KS];
+    typename F::thr_t theta[HVS_QB];
     uint32_t ra[HVS_QB], rb[HVS_QB];
 #pragma unroll
     for (int qb = 0; qb < HVS_QB; ++qb) {
         const uint32_t slot = (active ? g : gq) * HVS_GROUP + qb * 32u + (lane & 31u);
-        theta[qb] = B.theta[slot];
+        if constexpr (kI8)
+            theta[qb] = B.thetai[slot];
+        else
+            theta[qb] = B.theta[slot];
         ra[qb] = B.ra[slot];
         rb[qb] = B.rb[slot];
 #pragma unroll
-        for (int ks = 0; ks < HVS_KSTEPS; ++ks)
-            bq[qb][ks] = hvs_as_bf16x8(B.bfrag[((size_t)((active ? g : gq) * HVS_QB + qb) * HVS_KSTEPS + ks) * 64u + lane]);
+        for (int ks = 0; ks < KS; ++ks)
+            bq[qb][ks] = F::frag(B.bfrag[((size_t)((active ? g : gq) * HVS_QB + qb) * KS + ks) * 64u + lane]);
     }
     uint64_t* __restrict__ lbuf = sbuf[wv];
     uint32_t wcnt = 0;  // wave-uniform fill of lbuf
@@ -814,15 +1110,15 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // waited for its own chunks before any wave passes the barrier) and frees the current buffer
     // (every wave has finished its ds_reads of it).  One barrier per 4 tiles keeps the waves loosely coupled: a
     // wave that spends time on survivors of one tile catches up inside the stage.
-    constexpr int kChunksPerWave = (HVS_STAGE * HVS_KSTEPS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
+    constexpr int kChunksPerWave = (HVS_STAGE * KS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
     auto issue_chunks = [&](uint32_t buf, uint32_t first_tile, int k0, int k1) {
         for (int k = k0; k < k1; ++k) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + (uint32_t)HVS_WG_WAVES * (uint32_t)k;  // chunk of the stage
-            if (c >= HVS_STAGE * HVS_KSTEPS) break;
-            uint32_t tile = first_tile + c / HVS_KSTEPS;
+            if (c >= HVS_STAGE * KS) break;
+            uint32_t tile = first_tile + c / KS;
             if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
-            const uint4* src = tiles + (size_t)tile * HVS_TILE_U4 + (c % HVS_KSTEPS) * 64u + lane;
-            const uint4* dst = &stile[buf][(c / HVS_KSTEPS) * HVS_TILE_U4 + (c % HVS_KSTEPS) * 64u];
+            const uint4* src = tiles + (size_t)tile * TILE_U4 + (c % KS) * 64u + lane;
+            const uint4* dst = &stile[buf][(c / KS) * TILE_U4 + (c % KS) * 64u];
             // LDS byte address of the chunk (wave-uniform) goes to M0; the instruction adds lane*16.
             // Issued as inline asm on purpose: hipcc orders every later ds_read behind a
             // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise the prefetch
@@ -836,7 +1132,27 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                          : "memory");
         }
     };
-    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) { issue_chunks(buf, first_tile, 0, kChunksPerWave); };
+    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
+        issue_chunks(buf, first_tile, 0, kChunksPerWave);
+        if constexpr (kI8) {
+            // the stage's accumulator inits (4 tiles x 32 x int32 = 512 B, contiguous in storage order): one
+            // half-wave LDS-DMA by the last wave
+            if (__builtin_amdgcn_readfirstlane(wv) == HVS_WG_WAVES - 1u) {
+                uint32_t tile = first_tile + (lane >> 3);
+                if (tile >= I1) tile = I1 - 1u;
+                const uint4* src = nrm + (size_t)tile * HVS_I8_NRM_U4 + (lane & 7u);
+                const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)&snrm[buf][0]);
+                if (lane < HVS_STAGE * HVS_I8_NRM_U4) {
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src), "s"(lds_addr)
+                                 : "memory");
+                }
+            }
+        }
+    };
     auto stage_barrier = [&]() {
 #ifndef HVS_EXPERIMENT_NOSYNC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA chunks have landed
@@ -885,20 +1201,34 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 #endif
                 const uint32_t bp = bpos[i];  // scalar load; computing it (runtime division by radix-1) measured 4 % slower
                 ++nblocks;
-                hvs_bf16x8 af[HVS_KSTEPS];
+                typename F::frag_t af[KS];
     #pragma unroll
-                for (int ks = 0; ks < HVS_KSTEPS; ++ks) af[ks] = hvs_as_bf16x8(stile[cur][tt * HVS_TILE_U4 + ks * 64 + lane]);
+                for (int ks = 0; ks < KS; ++ks) af[ks] = F::frag(stile[cur][tt * TILE_U4 + ks * 64 + lane]);
+                // accumulator start: 0 (BF16: the norm term sits in k = 100..102) or the rows' nh (INT8):
+                // accumulator r of a lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> 4 broadcast b128 reads
+                typename F::acc_t acc0;
+                if constexpr (kI8) {
+    #pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const hvs_i32x4 v = hvs_as_i32x4(snrm[cur][tt * HVS_I8_NRM_U4 + 2 * g4 + (lane >> 5)]);
+                        acc0[4 * g4 + 0] = v[0];
+                        acc0[4 * g4 + 1] = v[1];
+                        acc0[4 * g4 + 2] = v[2];
+                        acc0[4 * g4 + 3] = v[3];
+                    }
+                } else {
+                    acc0 = typename F::acc_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                }
                 // four independent accumulation chains, then four epilogues: one scheduling region, so the
                 // v_max3 trees of one query block overlap the MFMAs of the next
-                hvs_f32x16 acc[HVS_QB];
+                typename F::acc_t acc[HVS_QB];
                 bool hit[HVS_QB];
-                float gm[HVS_QB][4];
+                typename F::thr_t gm[HVS_QB][4];
     #pragma unroll
                 for (int qb = 0; qb < HVS_QB; ++qb) {
-                    acc[qb] = hvs_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[qb] = F::mfma(af[0], bq[qb][0], acc0);
     #pragma unroll
-                    for (int ks = 0; ks < HVS_KSTEPS; ++ks)
-                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bq[qb][ks], acc[qb], 0, 0, 0);
+                    for (int ks = 1; ks < KS; ++ks) acc[qb] = F::mfma(af[ks], bq[qb][ks], acc[qb]);
                 }
                 bool anyhit = false;
     #pragma unroll
@@ -907,12 +1237,12 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                     // survivor scan first finds the group, then looks at its 4 accumulators only
     #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        gm[qb][k] = fmaxf(fmaxf(fmaxf(acc[qb][4 * k], acc[qb][4 * k + 1]), acc[qb][4 * k + 2]), acc[qb][4 * k + 3]);
-                    const float m = fmaxf(fmaxf(fmaxf(gm[qb][0], gm[qb][1]), gm[qb][2]), gm[qb][3]);
+                        gm[qb][k] = F::max2(F::max2(F::max2(acc[qb][4 * k], acc[qb][4 * k + 1]), acc[qb][4 * k + 2]), acc[qb][4 * k + 3]);
+                    const typename F::thr_t m = F::max2(F::max2(F::max2(gm[qb][0], gm[qb][1]), gm[qb][2]), gm[qb][3]);
                     // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
                     hit[qb] = (m >= theta[qb]) & (bp * 32u + 32u > ra[qb]) & (bp * 32u < rb[qb]);
     #ifdef HVS_EXPERIMENT_NOHIT
-                    hit[qb] = m == 12345.678f;  // keeps the max tree alive, (almost) never true: ceiling experiment
+                    hit[qb] = m == (typename F::thr_t)12345678;  // keeps the max tree alive, (almost) never true: ceiling experiment
     #endif
                     anyhit = anyhit | hit[qb];
                 }
@@ -1050,7 +1380,8 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
                                                    HvsBatch B, const HvsBounds* __restrict__ bounds, int final, int pad,
-                                                   uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+                                                   uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, int fmt,
+                                                   const HvsQuant* __restrict__ qz)
 {
     __shared__ uint64_t sbuf[4][256];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1095,6 +1426,27 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
             B.candcnt[slot] = 0;
             float tau = __builtin_inff();
             float theta = B.rb[slot] > B.ra[slot] ? -__builtin_inff() : __builtin_inff();
+            if (fmt == HVS_FMT_I8) {
+                // INT8 format (see "INT8 filter" above): S = qq.dq + nh is exact, the band has no accumulation term
+                int ti = B.rb[slot] > B.ra[slot] ? (int)0x80000000 : 0x7FFFFFFF;
+                if (cnt >= HVS_KNN) {
+                    tau = dmax;
+                    const double g = 20.0 * 5.9604644775390625e-08;
+                    const double iu = qz->inv_sd * qz->inv_sd;  // 1 / sd^2
+                    const double band = ((double)B.nqb[slot] * (double)bounds->e_d8 + (double)B.eq[slot] * (double)bounds->n_d8) *
+                                        (1.0 + 1e-6);
+                    // -2: one unit for nh = floor(.), one for the f64 evaluation of this expression (relative
+                    // 1e-9 of the magnitudes on top)
+                    double th = (0.5 * (B.qn[slot] * (1.0 - 1e-12) - (double)tau * (1.0 + 2.0 * g)) - band) * iu;
+                    th -= 2.0 + 1e-9 * (B.qn[slot] + (double)tau + band) * iu;
+                    th = floor(th);
+                    ti = th >= 2147483647.0 ? 0x7FFFFFFF : (th <= -2147483647.0 ? (int)0x80000001 : (int)th);
+                    if (!(th == th)) ti = (int)0x80000001;  // NaN cannot happen with finite inputs; keep everything
+                }
+                B.tau[slot] = tau;
+                B.thetai[slot] = ti;
+                return;
+            }
             if (cnt >= HVS_KNN) {
                 tau = dmax;
                 const double g = 20.0 * 5.9604644775390625e-08;

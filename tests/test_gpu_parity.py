@@ -15,10 +15,14 @@ PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
 GOLDENS = sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "*.npz")))
 
 
-@pytest.fixture(scope="module", params=[PKG.ENGINE_EXACT_SCAN, PKG.ENGINE_MFMA_FILTER], ids=["exact", "mfma"])
+FILTER_ENGINES = [PKG.ENGINE_MFMA_FILTER, PKG.ENGINE_MFMA_I8]
+FILTER_IDS = ["mfma_bf16", "mfma_i8"]
+
+
+@pytest.fixture(scope="module", params=[PKG.ENGINE_EXACT_SCAN] + FILTER_ENGINES, ids=["exact"] + FILTER_IDS)
 def eng(request):
-    """Both engines must give the same (bit-exact) answers: the FP32 exact-order scan and the BF16
-    MFMA bound filter + exact re-scoring."""
+    """All engines must give the same (bit-exact) answers: the FP32 exact-order scan and the BF16 / INT8
+    MFMA bound filters + exact re-scoring."""
     e = PKG.Engine(0)
     e.set_engine(request.param)
     e.engine_id = request.param
@@ -124,7 +128,7 @@ def test_resident_api_and_argument_errors(eng):
     T.check_parity(nodes, queries[100:600], ids, ref, got_dists=dists)
     t = eng.last_timing()
     assert t.nq == 500 and t.query_ms > 0 and t.engine == eng.engine_id and t.fallback_queries == 0
-    assert t.main_kernel_ms > 0 or eng.engine_id == PKG.ENGINE_MFMA_FILTER
+    assert t.main_kernel_ms > 0 or eng.engine_id in FILTER_ENGINES
     passing = sum(int(T._passes(nodes, q).sum()) for q in queries[100:600])
     assert t.pairs == passing
     with pytest.raises(PKG.HvsError):
@@ -164,8 +168,9 @@ def test_cli_driver_matches_reference_files(tmp_path):
     assert bad.returncode == 1 and "[source_path] [query_path] [output_path]" in bad.stdout
 
 
+@pytest.mark.parametrize("fengine", FILTER_ENGINES, ids=FILTER_IDS)
 @pytest.mark.parametrize("n", [2048 * 4 + 17, 70_000, 300_001])
-def test_mfma_engine_levels_and_ranges(n):
+def test_mfma_engine_levels_and_ranges(n, fengine):
     """Sizes that give 1, 2 and 3 index levels; queries of every type incl. empty and tiny ranges."""
     nodes = T.gen_data(n, 4000 + n, T.GEN_V1, 20)
     nodes[::997, 1] = np.nan                 # NaN timestamps never satisfy l <= T <= r but do satisfy C == v
@@ -179,18 +184,18 @@ def test_mfma_engine_levels_and_ranges(n):
     queries[4, :4] = [2, -1, np.nan, 1.0]    # NaN bound matches nothing
     queries[5, :4] = [2, -1, -np.inf, np.inf]
     with PKG.Engine(0) as e:
-        e.set_engine(PKG.ENGINE_MFMA_FILTER)
+        e.set_engine(fengine)
         e.load_data(nodes)
         ids, dists = e.query(queries, 1.0)
         t = e.last_timing()
-        assert t.engine == PKG.ENGINE_MFMA_FILTER and t.fallback_queries == 0
+        assert t.engine == fengine and t.fallback_queries == 0
         ref, _ = T.oracle_query(nodes, queries)
         T.check_parity(nodes, queries, ids, ref, got_dists=dists)
         passing = sum(int(T._passes(nodes, q).sum()) for q in queries)
         assert t.pairs == passing
         # sampled prefixes: the filter engine down to sn = n/4 (its exact stages drop rows >= sn), the exact
         # engine below that
-        for sp, want_engine in ((0.6, PKG.ENGINE_MFMA_FILTER), (0.3, PKG.ENGINE_MFMA_FILTER), (0.1, PKG.ENGINE_EXACT_SCAN)):
+        for sp, want_engine in ((0.6, fengine), (0.3, fengine), (0.1, PKG.ENGINE_EXACT_SCAN)):
             ids2, d2 = e.query(queries[:80], sp)
             t2 = e.last_timing()
             assert t2.engine == want_engine, (sp, t2.engine)
@@ -200,7 +205,8 @@ def test_mfma_engine_levels_and_ranges(n):
             assert t2.pairs == sum(int(T._passes(nodes[:sn], q).sum()) for q in queries[:80])
 
 
-def test_mfma_engine_overflow_falls_back_to_exact():
+@pytest.mark.parametrize("fengine", FILTER_ENGINES, ids=FILTER_IDS)
+def test_mfma_engine_overflow_falls_back_to_exact(fengine):
     """Thousands of rows at exactly the same distance overflow a candidate list; those queries are
     re-run by the exact engine and still match the canonical answer."""
     base = T.gen_data(1, 3)[0]
@@ -210,7 +216,7 @@ def test_mfma_engine_overflow_falls_back_to_exact():
     nodes[::7, 2:] += 0.5
     queries = T.gen_queries(64, 5, ncat=4)
     with PKG.Engine(0) as e:
-        e.set_engine(PKG.ENGINE_MFMA_FILTER)
+        e.set_engine(fengine)
         e.load_data(nodes)
         ids, dists = e.query(queries, 1.0)
         assert e.last_timing().fallback_queries > 0
@@ -230,6 +236,17 @@ def test_mfma_accumulation_error_is_inside_the_budget(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_int8_mfma_operand_layout(tmp_path):
+    """The INT8 filter's fragment layout and accumulator-init semantics of v_mfma_i32_32x32x32_i8: exact integers."""
+    import subprocess
+    exe = str(tmp_path / "mfma_i8_layout_check.out")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w",
+                    os.path.join(T.REPO, "tests", "mfma_i8_layout_check.hip"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_many_small_batches_and_nonfinite_inputs():
     """HVS_MFMA_BATCH / HVS_EXACT_BATCH split one call into many batches; queries or data with inf/NaN
     components are answered by the exact engine."""
@@ -243,7 +260,7 @@ PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
 nodes = T.gen_data(40000, 31, T.GEN_V1, 10); queries = T.gen_queries(700, 32, T.GEN_V1, 10)
 queries[5, 10] = np.inf; queries[6, 50] = 1e30
 ref, _ = T.oracle_query(nodes, queries)
-for engine in (1, 2):
+for engine in (1, 2, 3):
     with PKG.Engine(0) as e:
         e.set_engine(engine); e.load_data(nodes)
         ids, d = e.query(queries, 1.0)
@@ -251,7 +268,7 @@ for engine in (1, 2):
     ok = [i for i in range(700) if i not in (5, 6)]
     T.check_parity(nodes, queries[ok], ids[ok], ref[ok], got_dists=d[ok])
     assert t.engine == engine, (t.engine, engine)
-    if engine == 2: assert t.fallback_queries >= 2
+    if engine >= 2: assert t.fallback_queries >= 2
 bad = nodes.copy(); bad[123, 7] = np.inf
 with PKG.Engine(0) as e:
     e.set_engine(2); e.load_data(bad)
@@ -279,6 +296,17 @@ def test_full_size_d1e7_engines_agree_and_properties_hold():
         t = e.last_timing()
         ids, dists = e.download_results(0, nq)
         assert t.engine == PKG.ENGINE_MFMA_FILTER and t.fallback_queries == 0
+        # the INT8 filter (tiles rebuilt in that format) and the planner's own choice: same bits
+        for other in (PKG.ENGINE_MFMA_I8, PKG.ENGINE_AUTO):
+            e.set_engine(other)
+            e.query_resident(0, nq, 1.0)
+            e.sync()
+            t8 = e.last_timing()
+            ids8, dists8 = e.download_results(0, nq)
+            assert t8.engine in FILTER_ENGINES and t8.fallback_queries == 0
+            assert other != PKG.ENGINE_MFMA_I8 or t8.engine == PKG.ENGINE_MFMA_I8
+            assert np.array_equal(ids, ids8) and np.array_equal(dists.view(np.uint32), dists8.view(np.uint32))
+            print("engine", t8.engine, "rescored pairs/query", t8.rescored_pairs / nq, "(bf16:", t.rescored_pairs / nq, ")")
         # the same queries through the exact engine (first 1024: ~10^10 exact pairs)
         e.set_engine(PKG.ENGINE_EXACT_SCAN)
         e.query_resident(0, 1024, 1.0)
@@ -335,7 +363,7 @@ def test_clustered_data_parity_both_engines():
     queries = T.gen_queries(nq, 5, ncat=8)
     queries[:, 4:] = centers[rng.integers(0, ncl, nq)] + rng.normal(0, 0.05, (nq, 100)).astype(np.float32)
     ref, _ = T.oracle_query(nodes, queries)
-    for engine in (PKG.ENGINE_EXACT_SCAN, PKG.ENGINE_MFMA_FILTER):
+    for engine in [PKG.ENGINE_EXACT_SCAN] + FILTER_ENGINES:
         with PKG.Engine(0) as e:
             e.set_engine(engine)
             e.load_data(nodes)
@@ -345,7 +373,7 @@ def test_clustered_data_parity_both_engines():
         print("engine", engine, "fallback queries", t.fallback_queries, "rescored pairs/query", t.rescored_pairs / nq)
 
 
-@pytest.mark.parametrize("engine", [1, 2], ids=["exact", "mfma"])
+@pytest.mark.parametrize("engine", [1, 2, 3], ids=["exact"] + FILTER_IDS)
 def test_data_sharded_mode_virtual_ranks(engine):
     """D-sharded mode on one GPU: 3 contexts hold disjoint row ranges (padding off),
     a 4th holds the last 100 rows; sharding.merge_data_shards gives the whole-set answer."""
