@@ -1038,18 +1038,6 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
     c->timing.pairs = h[0];
     c->timing.scanned_pairs = h[1];
     c->timing.rescored_pairs = h[2];
-#ifdef HVS_DIAG_STAMPS
-    {
-        unsigned long long d[16];
-        HVS_HIP(c, hipMemcpy(d, c->d_counters, sizeof(d), hipMemcpyDeviceToHost));
-        if (d[13])
-            std::fprintf(stderr,
-                         "[diag last level] wave cycles: total %.3e  dma-issue %.1f%%  ds_read+mfma+epilogue %.1f%%  survivors %.1f%%  "
-                         "barrier %.1f%%  | per tile: compute %.0f, all %.0f cycles\n",
-                         (double)d[8], 100.0 * d[9] / d[8], 100.0 * d[10] / d[8], 100.0 * d[11] / d[8], 100.0 * d[12] / d[8],
-                         (double)d[10] / d[13], (double)d[8] / d[13]);
-    }
-#endif
     *out = c->timing;
     return HVS_OK;
 }

@@ -943,21 +943,23 @@ __global__ void hvs_k_count_prefix_pairs(HvsBatch B, const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// hvs_k_filter_mfma -- the dominant kernel.
+// hvs_k_filter_mfma<FMT> -- the dominant kernel (FMT = tile format: BF16 or INT8).
 //
 // Work item of a wave = (group of 4 query blocks = 128 queries, one level, one segment of <= HVS_SEG
 // row blocks of the level's storage).  A 256-thread workgroup = 4 waves = 4 consecutive groups on the
-// SAME segment: each 7 KiB tile is brought into LDS once per workgroup by LDS-DMA (stages of 4 tiles,
-// double-buffered, one barrier per stage) and read from there by all four waves.
+// SAME segment: each tile (BF16 7 KiB, INT8 4 KiB + 128 B of accumulator inits) is brought into LDS once per
+// workgroup by LDS-DMA (stages of 4 tiles, double-buffered, one barrier per stage) and read from there by
+// all four waves.
 //
-// Per tile and wave: 7 x ds_read_b128 fetch the A fragments; against each of the wave's 4 resident
-// query blocks (B fragments in 112 VGPRs) a chain of 7 v_mfma_f32_32x32x16_bf16 yields
-// s[row][query] = q.d - |d|^2/2; the four chains are interleaved k-step by k-step.  The 16
-// accumulators of a lane belong to ONE query (the lane's column), so the test "could this row still
-// enter the query's top-100"  s >= theta[query]  needs one v_max3 tree and one compare against a
-// per-lane constant.  Rare survivors are found by a v_cmp + scalar-branch scan of the 16 accumulators,
-// range-checked, packed as (slot << 32 | position) into a wave-private LDS buffer and flushed to the
-// group's pair list with one returning atomic per ~200 pairs.
+// Per tile and wave: ds_read_b128 fetch the A fragments (7 / 4); against each of the wave's 4 resident
+// query blocks (B fragments in 112 / 64 VGPRs) a chain of 7 v_mfma_f32_32x32x16_bf16 (resp. 4
+// v_mfma_i32_32x32x32_i8 started from the rows' integer norm terms) yields s[row][query] = q.d - |d|^2/2 (in the
+// format's units); the chains are interleaved k-step by k-step.  The 16 accumulators of a lane belong to ONE
+// query (the lane's column), so the test "could this row still enter the query's top-100"  s >= theta[query]
+// needs one v_max3 chain and one compare against a per-lane constant; blocks inside every lane's own position
+// range (wave-uniform test) skip the per-lane range test.  Survivors (about 0.8 per wave and tile) are found from
+// a per-lane bit mask of the accumulators (v_cmp + v_addc_co), range-checked, packed as (slot << 32 | position)
+// into a wave-private LDS buffer and flushed to the group's pair list with one returning atomic per ~200 pairs.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ hvs_bf16x8 hvs_as_bf16x8(const uint4& u)
 {
@@ -977,6 +979,48 @@ __device__ __forceinline__ hvs_i32x4 hvs_as_i32x4(const uint4& u)
     } c;
     c.u4 = u;
     return c.i4;
+}
+
+// Bit r of the result = (a_r >= th), for the 16 accumulators of a lane: v_cmp into a scalar pair + v_addc_co
+// (mask = 2 mask + carry) per accumulator, 33 VALU instructions.  (The compiler's own rendering of the same
+// expression is compare / select / or / shift plus hazard nops, about twice that.)  gfx950 wants two wait
+// states between a VALU writing a scalar pair and a VALU reading it: three pairs rotate, so every v_addc_co
+// reads a pair written at least four instructions earlier.  CMP is "v_cmp_ge_i32_e64" or "v_cmp_ge_f32_e64".
+#define HVS_HITMASK_ASM(CMP)                                                                                  \
+    "v_mov_b32 %0, 0\n\t" CMP " %1, %20, %21\n\t" CMP " %2, %19, %21\n\t" CMP " %3, %18, %21\n\t"                 \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t" CMP " %1, %17, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t" CMP " %2, %16, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t" CMP " %3, %15, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t" CMP " %1, %14, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t" CMP " %2, %13, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t" CMP " %3, %12, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t" CMP " %1, %11, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t" CMP " %2, %10, %21\n\t"                                         \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t" CMP " %3, %9, %21\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t" CMP " %1, %8, %21\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t" CMP " %2, %7, %21\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t" CMP " %3, %6, %21\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t" CMP " %1, %5, %21\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"                                                                 \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"                                                                 \
+    "s_nop 1\n\t"                                                                                             \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1"
+template <typename ACC, typename THR>
+__device__ __forceinline__ uint32_t hvs_hit_mask(const ACC& a, THR th)
+{
+    uint32_t m;
+    uint64_t s0, s1, s2, sc;
+    if constexpr (sizeof(THR) == 4 && ((THR)0.5f != (THR)0))  // float thresholds
+        asm volatile(HVS_HITMASK_ASM("v_cmp_ge_f32_e64")
+                     : "=&v"(m), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(sc)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]),
+                       "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(th));
+    else
+        asm volatile(HVS_HITMASK_ASM("v_cmp_ge_i32_e64")
+                     : "=&v"(m), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(sc)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]),
+                       "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(th));
+    return m;
 }
 
 // operand / accumulator types and the MFMA step of the two tile formats
@@ -1064,6 +1108,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         I1 = srange[w][1] > I1 ? srange[w][1] : I1;
     }
     if (I0 >= I1) return;  // uniform over the workgroup
+    I0 = __builtin_amdgcn_readfirstlane(I0);  // (read from LDS: tell the compiler they are scalars)
+    I1 = __builtin_amdgcn_readfirstlane(I1);
     i0 = __builtin_amdgcn_readfirstlane(i0);  // wave-uniform by construction: keep the tile test scalar
     i1 = __builtin_amdgcn_readfirstlane(i1);
     const bool active = i0 < i1;
@@ -1159,157 +1205,160 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         __syncthreads();
 #endif
     };
+    // ---- the tile loop ---------------------------------------------------------------------------------------
+    // Per tile: A fragments (+ INT8 accumulator inits) from LDS, the 4 chains (two pairs, each interleaved
+    // k-step by k-step), the 4 epilogues in the same scheduling region (their VALU work interleaves with the
+    // MFMA issue), then -- rarely -- the survivors.  (A hand-pipelined variant that overlapped one pair's
+    // epilogue with the other pair's chains across tiles measured 2-5 % slower: the second wave of the SIMD
+    // already fills those gaps.)
+    constexpr int HQ = HVS_QB / 2;
+    static_assert(HVS_QB % 2 == 0, "query blocks are processed in two halves");
+    typename F::frag_t af[KS];
+    typename F::acc_t acc0;
+    typename F::acc_t acc[HVS_QB];
+    bool hit[HVS_QB];
+    uint32_t bp = 0;
+
+    // A fragments and accumulator start of tile i from its stage buffer.  Start: 0 (BF16: the norm term sits in
+    // k = 100..102) or the rows' nh (INT8): accumulator r of a lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // -> 4 broadcast b128 reads
+    auto load_tile = [&](uint32_t i) {
+        const uint32_t rel = i - I0, buf = (rel / HVS_STAGE) & 1u, tt = rel % HVS_STAGE;
+    #pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = F::frag(stile[buf][tt * TILE_U4 + ks * 64 + lane]);
+        if constexpr (kI8) {
+    #pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const hvs_i32x4 v = hvs_as_i32x4(snrm[buf][tt * HVS_I8_NRM_U4 + 2 * g4 + (lane >> 5)]);
+                acc0[4 * g4 + 0] = v[0];
+                acc0[4 * g4 + 1] = v[1];
+                acc0[4 * g4 + 2] = v[2];
+                acc0[4 * g4 + 3] = v[3];
+            }
+        } else {
+            acc0 = typename F::acc_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        bp = __builtin_amdgcn_readfirstlane(bpos[i]);  // scalar load; computing it (runtime division by radix-1) measured 4 % slower
+    };
+    // the chains of one pair, interleaved k-step by k-step
+    auto chains = [&](int pair) {
+    #pragma unroll
+        for (int h = 0; h < HQ; ++h) acc[pair * HQ + h] = F::mfma(af[0], bq[pair * HQ + h][0], acc0);
+    #pragma unroll
+        for (int ks = 1; ks < KS; ++ks) {
+    #pragma unroll
+            for (int h = 0; h < HQ; ++h) acc[pair * HQ + h] = F::mfma(af[ks], bq[pair * HQ + h][ks], acc[pair * HQ + h]);
+        }
+    };
+    // max tree + threshold + range test of one pair on the tile at block position bpx; true when any lane hits
+    auto epilogue = [&](int pair, uint32_t bpx, bool inner) -> bool {
+        bool anyhit = false;
+    #pragma unroll
+        for (int h = 0; h < HQ; ++h) {
+            const int qb = pair * HQ + h;
+            typename F::thr_t m = F::max2(F::max2(acc[qb][0], acc[qb][1]), acc[qb][2]);  // v_max3 chain
+    #pragma unroll
+            for (int r = 3; r < 15; r += 2) m = F::max2(F::max2(m, acc[qb][r]), acc[qb][r + 1]);
+            m = F::max2(m, acc[qb][15]);
+            // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
+            hit[qb] = m >= theta[qb];
+            if (!inner) hit[qb] = hit[qb] & (bpx * 32u + 32u > ra[qb]) & (bpx * 32u < rb[qb]);
+    #ifdef HVS_EXPERIMENT_NOHIT
+            hit[qb] = m == (typename F::thr_t)12345678;  // keeps the max tree alive, (almost) never true: ceiling experiment
+    #endif
+            anyhit = anyhit | hit[qb];
+        }
+        return __ballot(anyhit) != 0ull;
+    };
+    // Survivors of one pair (about every second tile has one somewhere in the wave).  Kept SMALL on purpose:
+    // a fully unrolled scan (one compare + branch + append per accumulator, 64 copies) is ~30 KiB of code that
+    // is entered at a random place each time and misses the instruction cache; here a query block with a hit
+    // builds a per-lane bit mask of its 16 accumulators in straight-line code and one short loop per block
+    // extracts the set bits (usually one bit in one lane -> one trip).
+    auto survivors = [&](int pair, uint32_t bpx) {
+    #pragma unroll
+        for (int h = 0; h < HQ; ++h) {
+            const int qb = pair * HQ + h;
+            if (__ballot(hit[qb]) == 0ull) continue;
+            uint32_t mask = hvs_hit_mask(acc[qb], theta[qb]);
+            const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+            const uint32_t a = ra[qb], b = rb[qb];
+            const uint32_t rowbase = bpx * 32u + 4u * (lane >> 5);
+            for (;;) {
+                if (__ballot(mask != 0u) == 0ull) break;
+                const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this lane has nothing left
+                mask &= mask - 1u;
+                const uint32_t pos = rowbase + (r & 3u) + 8u * (r >> 2);
+                const bool c = r < 16u && pos >= a && pos < b;
+                const uint64_t cm = __ballot(c);
+                if (c) lbuf[wcnt + hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | pos;
+                wcnt += (uint32_t)__popcll(cm);
+                if (wcnt > 192u) flush();
+            }
+        }
+    };
+    auto valid = [&](uint32_t i) { return active && i >= i0 && i < i1; };  // wave-uniform
+
+    // the positions every lane's range covers: [ra_max, rb_min) (lanes that can never hit do not count)
+    uint32_t ra_max = 0u, rb_min = 0xFFFFFFFFu;
+    #pragma unroll
+    for (int qb = 0; qb < HVS_QB; ++qb) {
+        const bool live = rb[qb] > ra[qb];
+        ra_max = max(ra_max, live ? ra[qb] : 0u);
+        rb_min = min(rb_min, live ? rb[qb] : 0xFFFFFFFFu);
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ra_max = max(ra_max, (uint32_t)__shfl_xor((int)ra_max, o));
+        rb_min = min(rb_min, (uint32_t)__shfl_xor((int)rb_min, o));
+    }
+    ra_max = __builtin_amdgcn_readfirstlane(ra_max);
+    rb_min = __builtin_amdgcn_readfirstlane(rb_min);
+
+    // tile at a time: four chains, four epilogues, survivors
     const uint32_t nstage = hvs_ceil_div(I1 - I0, HVS_STAGE);
-#ifdef HVS_DIAG_STAMPS
-    // diagnostic build only (never timed): where a wave's cycles go; sums leave through counters[8..13]
-    unsigned long long tg_dma = 0, tg_comp = 0, tg_slow = 0, tg_bar = 0, tg_tiles = 0, ta, tb, tc, td;
-#define HVS_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-    unsigned long long ts_begin;
-    HVS_STAMP(ts_begin);
-#endif
     issue_stage(0u, I0);
     stage_barrier();
+    // Everything loaded so far (B fragments, thresholds, ranges) has landed -- the stage barrier waited for
+    // vmcnt(0) -- but the compiler cannot see through that inline asm and would re-wait for those loads at
+    // their first uses INSIDE the loop (`s_waitcnt vmcnt(0)` in the middle of every tile's MFMA block, which
+    // with the LDS-DMA prefetch of the next stage in flight exposes the DMA latency once per stage).  A wait
+    // the compiler does understand, once, here, clears its scoreboard.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    auto tile_body = [&](uint32_t bpx, bool inner) {
+        chains(0);
+        chains(1);
+        const bool h0 = epilogue(0, bpx, inner);
+        const bool h1 = epilogue(1, bpx, inner);
+        if (h0 | h1) {
+            survivors(0, bpx);
+            survivors(1, bpx);
+        }
+    };
     for (uint32_t st = 0; st < nstage; ++st) {
-        const uint32_t cur = st & 1u;
-#ifdef HVS_DIAG_STAMPS
-        HVS_STAMP(ta);
-#endif
 #ifndef HVS_EXPERIMENT_NODMA
-#ifdef HVS_STAGGER
-        // 8-wave workgroups: the two waves of a SIMD (w and w+4) issue their LDS-DMA in different halves of
-        // the stage, so one of them multiplies while the other feeds the next stage
-        if (st + 1u < nstage && __builtin_amdgcn_readfirstlane(wv) < 4u) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
-#else
-        if (st + 1u < nstage) issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
-#endif
-#endif
-#ifdef HVS_DIAG_STAMPS
-        HVS_STAMP(tb);
-        tg_dma += tb - ta;
+        if (st + 1u < nstage) issue_stage((st & 1u) ^ 1u, I0 + (st + 1u) * HVS_STAGE);
 #endif
 #pragma unroll 1
         for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
             const uint32_t i = I0 + st * HVS_STAGE + tt;
             if (i >= I1) break;
-#ifdef HVS_STAGGER
-            if (tt == HVS_STAGE / 2 && st + 1u < nstage && __builtin_amdgcn_readfirstlane(wv) >= 4u)
-                issue_stage(cur ^ 1u, I0 + (st + 1u) * HVS_STAGE);
-#endif
-            if (active && i >= i0 && i < i1) {  // wave-uniform
-#ifdef HVS_DIAG_STAMPS
-                HVS_STAMP(tb);
-#endif
-                const uint32_t bp = bpos[i];  // scalar load; computing it (runtime division by radix-1) measured 4 % slower
+            if (valid(i)) {
                 ++nblocks;
-                typename F::frag_t af[KS];
-    #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) af[ks] = F::frag(stile[cur][tt * TILE_U4 + ks * 64 + lane]);
-                // accumulator start: 0 (BF16: the norm term sits in k = 100..102) or the rows' nh (INT8):
-                // accumulator r of a lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> 4 broadcast b128 reads
-                typename F::acc_t acc0;
-                if constexpr (kI8) {
-    #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const hvs_i32x4 v = hvs_as_i32x4(snrm[cur][tt * HVS_I8_NRM_U4 + 2 * g4 + (lane >> 5)]);
-                        acc0[4 * g4 + 0] = v[0];
-                        acc0[4 * g4 + 1] = v[1];
-                        acc0[4 * g4 + 2] = v[2];
-                        acc0[4 * g4 + 3] = v[3];
-                    }
-                } else {
-                    acc0 = typename F::acc_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                }
-                // four independent accumulation chains, then four epilogues: one scheduling region, so the
-                // v_max3 trees of one query block overlap the MFMAs of the next
-                typename F::acc_t acc[HVS_QB];
-                bool hit[HVS_QB];
-                typename F::thr_t gm[HVS_QB][4];
-    #pragma unroll
-                for (int qb = 0; qb < HVS_QB; ++qb) {
-                    acc[qb] = F::mfma(af[0], bq[qb][0], acc0);
-    #pragma unroll
-                    for (int ks = 1; ks < KS; ++ks) acc[qb] = F::mfma(af[ks], bq[qb][ks], acc[qb]);
-                }
-                bool anyhit = false;
-    #pragma unroll
-                for (int qb = 0; qb < HVS_QB; ++qb) {
-                    // maxima of the four groups of 4 accumulators (4 consecutive rows each) are kept: the
-                    // survivor scan first finds the group, then looks at its 4 accumulators only
-    #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        gm[qb][k] = F::max2(F::max2(F::max2(acc[qb][4 * k], acc[qb][4 * k + 1]), acc[qb][4 * k + 2]), acc[qb][4 * k + 3]);
-                    const typename F::thr_t m = F::max2(F::max2(F::max2(gm[qb][0], gm[qb][1]), gm[qb][2]), gm[qb][3]);
-                    // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
-                    hit[qb] = (m >= theta[qb]) & (bp * 32u + 32u > ra[qb]) & (bp * 32u < rb[qb]);
-    #ifdef HVS_EXPERIMENT_NOHIT
-                    hit[qb] = m == (typename F::thr_t)12345678;  // keeps the max tree alive, (almost) never true: ceiling experiment
-    #endif
-                    anyhit = anyhit | hit[qb];
-                }
-#ifdef HVS_DIAG_STAMPS
-                HVS_STAMP(tc);
-                tg_comp += tc - tb;
-                tg_tiles += 1;
-#endif
-                if (__ballot(anyhit) != 0ull) {
-    #pragma unroll
-                    for (int qb = 0; qb < HVS_QB; ++qb) {
-                        if (__ballot(hit[qb]) == 0ull) continue;
-                        const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
-    #pragma unroll
-                        for (int k4 = 0; k4 < 4; ++k4) {
-                            if (__ballot(gm[qb][k4] >= theta[qb]) == 0ull) continue;  // nothing in this group of 4
-    #pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) {
-                                const int r = 4 * k4 + rr;
-                                // cheap scan: one v_cmp + one scalar branch per accumulator; the range check
-                                // and the append only run for the rare accumulator that beats the threshold
-                                const uint64_t m0 = __ballot(acc[qb][r] >= theta[qb]);
-                                if (m0 != 0ull) {
-                                    const uint32_t pos =
-                                        bp * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                                    const bool c = acc[qb][r] >= theta[qb] && pos >= ra[qb] && pos < rb[qb];
-                                    const uint64_t mask = __ballot(c);
-                                    if (mask != 0ull) {
-                                        if (c) lbuf[wcnt + hvs_prefix_count(mask)] = ((uint64_t)slot << 32) | pos;
-                                        wcnt += (uint32_t)__popcll(mask);
-                                        if (wcnt > 192u) flush();
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-#ifdef HVS_DIAG_STAMPS
-                HVS_STAMP(td);
-                tg_slow += td - tc;
-#endif
+                load_tile(i);
+                wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+                const bool inner = bp * 32u >= ra_max && bp * 32u + 32u <= rb_min;
+                if (inner)
+                    tile_body(bp, true);
+                else
+                    tile_body(bp, false);
             }
         }
-#ifdef HVS_DIAG_STAMPS
-        HVS_STAMP(tc);
-#endif
         stage_barrier();
-#ifdef HVS_DIAG_STAMPS
-        HVS_STAMP(td);
-        tg_bar += td - tc;
-#endif
     }
     if (active) {
         flush();
         if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
-#ifdef HVS_DIAG_STAMPS
-        unsigned long long ts_end;
-        HVS_STAMP(ts_end);
-        if (lane == 0u && level == L.K) {
-            atomicAdd(&counters[8], ts_end - ts_begin);
-            atomicAdd(&counters[9], tg_dma);
-            atomicAdd(&counters[10], tg_comp);
-            atomicAdd(&counters[11], tg_slow);
-            atomicAdd(&counters[12], tg_bar);
-            atomicAdd(&counters[13], tg_tiles);
-        }
-#endif
     }
 }
 
