@@ -786,7 +786,7 @@ void hvs_destroy(hvs_ctx* c)
         HvsBatch& B = c->fb;
         void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
                       B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
-                      c->d_bounds, c->d_layout, c->d_ovf_list, c->d_ovf_count};
+                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count};
         for (void* p : fp)
             if (p) (void)hipFree(p);
     }

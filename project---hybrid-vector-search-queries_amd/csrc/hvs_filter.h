@@ -41,9 +41,14 @@
 #define HVS_GROUP (32 * HVS_QB)
 #define HVS_FCAP 1024         // per-query candidate keys per round
 #define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
+#ifndef HVS_SEG
 #define HVS_SEG 128           // row blocks per filter work item
+#endif
 #ifndef HVS_STAGE
-#define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage)
+#define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage), BF16 tiles (7 KiB)
+#endif
+#ifndef HVS_STAGE_I8
+#define HVS_STAGE_I8 8        // the same for INT8 tiles (4 KiB): 2 x 33 KiB of LDS per workgroup
 #endif
 #ifndef HVS_RADIX2_LEVELS
 #define HVS_RADIX2_LEVELS 14u  // how many of the last levels double (rather than quadruple) the rows seen (all)
@@ -550,9 +555,14 @@ struct HvsBins {
 __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
-    atomicAdd(&counts[hvs_type_rank(p.type)], 1u);
+    uint32_t rank = 0xFFu;
+    if (i < nq) rank = hvs_type_rank(hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS).type);
+    // one atomic per wave and class (one per query serialises 262144 atomics on 5 addresses: 1.4 ms)
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) {
+        const uint32_t c = (uint32_t)__popcll(__ballot(rank == k));
+        if (c && (threadIdx.x & 63u) == 0u) atomicAdd(&counts[k], c);
+    }
 }
 
 __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
@@ -1067,9 +1077,10 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     constexpr int KS = F::KSTEPS;
     constexpr int TILE_U4 = KS * 64;
     constexpr bool kI8 = FMT == HVS_FMT_I8;
+    constexpr int STG = kI8 ? HVS_STAGE_I8 : HVS_STAGE;  // tiles per LDS stage
     // two stages of 4 A tiles shared by the 4 waves (BF16: 2 x 28 KiB, INT8: 2 x 16 KiB + the rows' accumulator inits)
-    __shared__ uint4 stile[2][HVS_STAGE * TILE_U4];
-    __shared__ uint4 snrm[2][kI8 ? HVS_STAGE * HVS_I8_NRM_U4 : 1];
+    __shared__ uint4 stile[2][STG * TILE_U4];
+    __shared__ uint4 snrm[2][kI8 ? STG * HVS_I8_NRM_U4 : 1];
     __shared__ uint64_t sbuf[HVS_WG_WAVES][256];         // wave-private survivor buffers
     __shared__ uint32_t srange[HVS_WG_WAVES][2];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1156,11 +1167,11 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // waited for its own chunks before any wave passes the barrier) and frees the current buffer
     // (every wave has finished its ds_reads of it).  One barrier per 4 tiles keeps the waves loosely coupled: a
     // wave that spends time on survivors of one tile catches up inside the stage.
-    constexpr int kChunksPerWave = (HVS_STAGE * KS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
+    constexpr int kChunksPerWave = (STG * KS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
     auto issue_chunks = [&](uint32_t buf, uint32_t first_tile, int k0, int k1) {
         for (int k = k0; k < k1; ++k) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + (uint32_t)HVS_WG_WAVES * (uint32_t)k;  // chunk of the stage
-            if (c >= HVS_STAGE * KS) break;
+            if (c >= STG * KS) break;
             uint32_t tile = first_tile + c / KS;
             if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
             const uint4* src = tiles + (size_t)tile * TILE_U4 + (c % KS) * 64u + lane;
@@ -1189,7 +1200,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                 const uint4* src = nrm + (size_t)tile * HVS_I8_NRM_U4 + (lane & 7u);
                 const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
                     (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)&snrm[buf][0]);
-                if (lane < HVS_STAGE * HVS_I8_NRM_U4) {
+                if (lane < STG * HVS_I8_NRM_U4) {
                     uint32_t keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep)
@@ -1223,7 +1234,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // k = 100..102) or the rows' nh (INT8): accumulator r of a lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     // -> 4 broadcast b128 reads
     auto load_tile = [&](uint32_t i) {
-        const uint32_t rel = i - I0, buf = (rel / HVS_STAGE) & 1u, tt = rel % HVS_STAGE;
+        const uint32_t rel = i - I0, buf = (rel / STG) & 1u, tt = rel % STG;
     #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = F::frag(stile[buf][tt * TILE_U4 + ks * 64 + lane]);
         if constexpr (kI8) {
@@ -1316,7 +1327,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     rb_min = __builtin_amdgcn_readfirstlane(rb_min);
 
     // tile at a time: four chains, four epilogues, survivors
-    const uint32_t nstage = hvs_ceil_div(I1 - I0, HVS_STAGE);
+    const uint32_t nstage = hvs_ceil_div(I1 - I0, STG);
     issue_stage(0u, I0);
     stage_barrier();
     // Everything loaded so far (B fragments, thresholds, ranges) has landed -- the stage barrier waited for
@@ -1337,11 +1348,11 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     };
     for (uint32_t st = 0; st < nstage; ++st) {
 #ifndef HVS_EXPERIMENT_NODMA
-        if (st + 1u < nstage) issue_stage((st & 1u) ^ 1u, I0 + (st + 1u) * HVS_STAGE);
+        if (st + 1u < nstage) issue_stage((st & 1u) ^ 1u, I0 + (st + 1u) * STG);
 #endif
 #pragma unroll 1
-        for (uint32_t tt = 0; tt < HVS_STAGE; ++tt) {
-            const uint32_t i = I0 + st * HVS_STAGE + tt;
+        for (uint32_t tt = 0; tt < STG; ++tt) {
+            const uint32_t i = I0 + st * STG + tt;
             if (i >= I1) break;
             if (valid(i)) {
                 ++nblocks;
@@ -1363,16 +1374,23 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 }
 
 // ---------------------------------------------------------------------------------------------
-// hvs_k_rescore -- exact-order distances of the filter's survivors: one lane per (slot,pos) pair,
-// the same arithmetic as everywhere else (hvs_exact_dist), key appended to the slot's list.
+// hvs_k_rescore -- exact-order distances of the filter's survivors, key appended to the slot's list.
+//
+// EIGHT lanes per (slot,pos) pair, lane j playing AVX lane j of the reference (optimized_impl.h:96-125):
+// it accumulates dims j, 8+j, ..., 88+j (and 92+j for j >= 4: the masked tail) in that order, then the
+// horizontal sum ((a0+a4)+(a1+a5))+((a2+a6)+(a3+a7)) runs across the 8 lanes (xor 4, xor 1, xor 2; f32
+// addition is commutative, so every lane ends with the same bits as the sequential hvs_exact_dist).
+// The point is the memory access: one load instruction of a wave reads 8 rows x 32 contiguous bytes, and the
+// four instructions that walk one 128-byte line follow each other directly.  (One lane per pair -- 64 rows
+// x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
+// re-fetched lines from L2/HBM many times: 43 ms per 381 M pairs.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
                                                      HvsBatch B, const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
                                                      unsigned long long* __restrict__ counters)
 {
-    // the group's 128 query vectors are staged in LDS once per block (51 KB): a lane then reads its
-    // pair's query with ds_read_b128 and only the data row is gathered from global memory
+    // the group's 128 query vectors are staged in LDS once per block (51 KB)
     __shared__ float sq[HVS_GROUP][HVS_NDIM];
     const uint32_t g = blockIdx.y;
     uint32_t np = B.paircnt[g];
@@ -1385,7 +1403,8 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
             for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
         }
     }
-    if (blockIdx.x * blockDim.x >= np) return;  // uniform over the block
+    constexpr uint32_t kPairsPerBlock = 256u / 8u;
+    if (blockIdx.x * kPairsPerBlock >= np) return;  // uniform over the block
     for (uint32_t e = threadIdx.x; e < HVS_GROUP * (HVS_NDIM / 4); e += blockDim.x) {
         const uint32_t ql = e / (HVS_NDIM / 4), c4 = e % (HVS_NDIM / 4);
         const uint32_t qi = B.qid[g * HVS_GROUP + ql];
@@ -1395,15 +1414,38 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
     }
     __syncthreads();
     const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
-        const uint64_t pr = B.pairs[(size_t)g * HVS_GCAP + e];
+    const uint32_t j = threadIdx.x & 7u;
+    for (uint32_t base = blockIdx.x * kPairsPerBlock; base < np; base += gridDim.x * kPairsPerBlock) {  // uniform
+        const uint32_t e = base + (threadIdx.x >> 3);
+        const bool have = e < np;
+        const uint64_t pr = have ? B.pairs[(size_t)g * HVS_GCAP + e] : ((uint64_t)(g * HVS_GROUP) << 32);
         const uint32_t slot = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
-        const uint32_t id = perm[pos];
-        if (id >= sn) continue;  // sampled prefix (sample_proportion < 1): the filter does not know about it
-        const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
+        const uint32_t id = have ? perm[pos] : 0u;
+        // sampled prefix (sample_proportion < 1): the filter does not know about it
+        const bool ok = have && id < sn;
+        const float* __restrict__ dv = D + (size_t)(ok ? id : 0u) * HVS_DCOLS + 2;
         const float* qv = &sq[slot - g * HVS_GROUP][0];
-        const float dist = hvs_exact_dist(dv, qv);
-        if (dist <= B.tau[slot]) {
+        float dk[13];
+    #pragma unroll
+        for (int b = 0; b < 12; ++b) dk[b] = dv[8 * b + j];
+        dk[12] = dv[92u + (j | 4u)];
+        float acc = 0.0f;
+    #pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            float t = dk[b] - qv[8 * b + j];
+            t = t * t;
+            acc = acc + t;
+        }
+        {
+            float t = dk[12] - qv[92u + (j | 4u)];
+            t = t * t;
+            const float with_tail = acc + t;
+            acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
+        }
+        const float s = acc + __shfl_xor(acc, 4);
+        const float a = s + __shfl_xor(s, 1);
+        const float dist = a + __shfl_xor(a, 2);
+        if (ok && j == 0u && dist <= B.tau[slot]) {
             const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
             if (k < HVS_FCAP)
                 B.cand[(size_t)slot * HVS_FCAP + k] = hvs_make_key(dist, id);

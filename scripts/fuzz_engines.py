@@ -1,4 +1,4 @@
-"""Differential fuzzing on a GPU box: the MFMA engine must return the exact engine's bits (ids AND
+"""Differential fuzzing on a GPU box: the MFMA engines (BF16 and INT8 filters) must return the exact engine's bits (ids AND
 distances) for random data shapes, category counts, value ranges, special attribute values, query
 mixes and sample proportions.  Prints one line per case; exits 1 on the first mismatch."""
 import importlib, sys, time
@@ -19,6 +19,13 @@ def case(rng, i):
     if rng.random() < 0.3:   # clustered vectors / duplicates
         base = nodes[rng.integers(0, n, max(2, n // 50)), 2:]
         nodes[:, 2:] = base[rng.integers(0, base.shape[0], n)] + rng.normal(0, 0.01 * scale, (n, 100)).astype(np.float32) * (rng.random() < 0.5)
+    if rng.random() < 0.3:   # uneven dimensions, heavy tails, queries outside the data's bounding box (INT8 clipping)
+        dimscale = np.power(10.0, rng.uniform(-2, 2, 100)).astype(np.float32)
+        nodes[:, 2:] *= dimscale; queries[:, 4:] *= dimscale
+    if rng.random() < 0.3:
+        nodes[rng.integers(0, n, max(1, n // 500)), 2:] *= np.float32(rng.choice([3.0, 30.0]))
+        queries[rng.integers(0, nq, max(1, nq // 10)), 4:] *= np.float32(rng.choice([-2.0, 5.0]))
+        queries[rng.integers(0, nq, max(1, nq // 10)), 4 + int(rng.integers(0, 100))] += np.float32(100.0 * scale)
     if rng.random() < 0.3:
         k = max(1, n // 97)
         nodes[rng.integers(0, n, k), 1] = np.nan
@@ -29,15 +36,15 @@ def case(rng, i):
         queries[3, :4] = [2, -1, np.nan, 1]; queries[4, :4] = [1, -0.0, -1, -1]; queries[5, :4] = [3, 1, 0.3, 0.3]
     sp = float(rng.choice([1.0, 1.0, 1.0, 0.9, 0.5, 0.26, 0.1]))
     res = []
-    for engine in (1, 2):
+    for engine in (1, 2, 3):
         with PKG.Engine(0) as e:
             e.set_engine(engine); e.load_data(nodes)
             ids, d = e.query(queries, sp); t = e.last_timing()
         res.append((ids, d, t.engine, t.fallback_queries))
-    same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
-    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} engines={res[0][2]},{res[1][2]} fallback={res[1][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
+    same = all(np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) for r in res[1:])
+    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} engines={res[0][2]},{res[1][2]},{res[2][2]} fallback={res[1][3]},{res[2][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
     if not same:
-        bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1))[0]
+        bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1) | (res[0][0] != res[2][0]).any(axis=1))[0]
         print("  first bad queries:", bad[:10], queries[bad[:3], :4]); np.savez("gpurun_out/fuzz_fail.npz", nodes=nodes, queries=queries, sp=sp)
     if n <= 5000 and nq <= 129:   # small cases also against the oracle
         ref, _ = T.oracle_query(nodes, queries, sp)
