@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     typename F::frag_t af[KS];
     typename F::acc_t acc0;
     typename F::acc_t acc[HVS_QB];
-    bool hit[HVS_QB];
+    uint64_t hm[HVS_QB];
     uint32_t bp = 0;
 
     // A fragments and accumulator start of tile i from its stage buffer.  Start: 0 (BF16: the norm term sits in
@@ -1261,9 +1261,10 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
             for (int h = 0; h < HQ; ++h) acc[pair * HQ + h] = F::mfma(af[ks], bq[pair * HQ + h][ks], acc[pair * HQ + h]);
         }
     };
-    // max tree + threshold + range test of one pair on the tile at block position bpx; true when any lane hits
-    auto epilogue = [&](int pair, uint32_t bpx, bool inner) -> bool {
-        bool anyhit = false;
+    // max chain + threshold (+ range test) of one pair on the tile at block position bpx.  hm[qb] = lanes
+    // (queries) of the block with an accumulator at or above their threshold -- kept as SCALAR lane masks so
+    // that every later "anything to do?" test is a scalar compare, not a vector compare + branch.
+    auto epilogue = [&](int pair, uint32_t bpx, bool inner) {
     #pragma unroll
         for (int h = 0; h < HQ; ++h) {
             const int qb = pair * HQ + h;
@@ -1271,42 +1272,35 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     #pragma unroll
             for (int r = 3; r < 15; r += 2) m = F::max2(F::max2(m, acc[qb][r]), acc[qb][r + 1]);
             m = F::max2(m, acc[qb][15]);
-            // bitwise on purpose: '&&' compiles to exec-mask save/restore pairs between the MFMAs
-            hit[qb] = m >= theta[qb];
-            if (!inner) hit[qb] = hit[qb] & (bpx * 32u + 32u > ra[qb]) & (bpx * 32u < rb[qb]);
+            hm[qb] = __ballot(m >= theta[qb]);
+            if (!inner) hm[qb] &= __ballot((bpx * 32u + 32u > ra[qb]) & (bpx * 32u < rb[qb]));
     #ifdef HVS_EXPERIMENT_NOHIT
-            hit[qb] = m == (typename F::thr_t)12345678;  // keeps the max tree alive, (almost) never true: ceiling experiment
+            hm[qb] = __ballot(m == (typename F::thr_t)12345678);  // keeps the max chain alive, (almost) never true: ceiling experiment
     #endif
-            anyhit = anyhit | hit[qb];
         }
-        return __ballot(anyhit) != 0ull;
     };
-    // Survivors of one pair (about every second tile has one somewhere in the wave).  Kept SMALL on purpose:
-    // a fully unrolled scan (one compare + branch + append per accumulator, 64 copies) is ~30 KiB of code that
-    // is entered at a random place each time and misses the instruction cache; here a query block with a hit
-    // builds a per-lane bit mask of its 16 accumulators in straight-line code and one short loop per block
-    // extracts the set bits (usually one bit in one lane -> one trip).
-    auto survivors = [&](int pair, uint32_t bpx) {
-    #pragma unroll
-        for (int h = 0; h < HQ; ++h) {
-            const int qb = pair * HQ + h;
-            if (__ballot(hit[qb]) == 0ull) continue;
-            uint32_t mask = hvs_hit_mask(acc[qb], theta[qb]);
-            const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
-            const uint32_t a = ra[qb], b = rb[qb];
-            const uint32_t rowbase = bpx * 32u + 4u * (lane >> 5);
-            for (;;) {
-                if (__ballot(mask != 0u) == 0ull) break;
-                const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this lane has nothing left
-                mask &= mask - 1u;
-                const uint32_t pos = rowbase + (r & 3u) + 8u * (r >> 2);
-                const bool c = r < 16u && pos >= a && pos < b;
-                const uint64_t cm = __ballot(c);
-                if (c) lbuf[wcnt + hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | pos;
-                wcnt += (uint32_t)__popcll(cm);
-                if (wcnt > 192u) flush();
-            }
-        }
+    // Survivors of one query block (about one wave-tile in ten at the top level, every tile at the low ones).
+    // Kept SMALL on purpose: a fully unrolled scan (one compare + branch + append per accumulator, 64 copies)
+    // is ~30 KiB of code entered at a random place each time; here the block builds a per-lane bit mask of its
+    // 16 accumulators in straight-line code and one short loop extracts the set bits (usually one bit in one
+    // lane -> one trip).  The loop's exit test is issued right after the mask update, ahead of the append.
+    auto survivors = [&](int qb, uint32_t bpx) {
+        uint32_t mask = hvs_hit_mask(acc[qb], theta[qb]);
+        const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
+        const uint32_t a = ra[qb], b = rb[qb];
+        const uint32_t rowbase = bpx * 32u + 4u * (lane >> 5);
+        uint64_t more;
+        do {
+            const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this lane has nothing (left)
+            mask &= mask - 1u;
+            more = __ballot(mask != 0u);
+            const uint32_t pos = rowbase + (r & 3u) + 8u * (r >> 2);
+            const bool c = r < 16u && pos >= a && pos < b;
+            const uint64_t cm = __ballot(c);
+            if (c) lbuf[wcnt + hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | pos;
+            wcnt += (uint32_t)__popcll(cm);
+            if (wcnt > 192u) flush();
+        } while (more != 0ull);
     };
     auto valid = [&](uint32_t i) { return active && i >= i0 && i < i1; };  // wave-uniform
 
@@ -1339,11 +1333,15 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     auto tile_body = [&](uint32_t bpx, bool inner) {
         chains(0);
         chains(1);
-        const bool h0 = epilogue(0, bpx, inner);
-        const bool h1 = epilogue(1, bpx, inner);
-        if (h0 | h1) {
-            survivors(0, bpx);
-            survivors(1, bpx);
+        epilogue(0, bpx, inner);
+        epilogue(1, bpx, inner);
+        uint64_t any = 0;
+    #pragma unroll
+        for (int qb = 0; qb < HVS_QB; ++qb) any |= hm[qb];
+        if (any != 0ull) {
+    #pragma unroll
+            for (int qb = 0; qb < HVS_QB; ++qb)
+                if (hm[qb] != 0ull) survivors(qb, bpx);
         }
     };
     for (uint32_t st = 0; st < nstage; ++st) {
