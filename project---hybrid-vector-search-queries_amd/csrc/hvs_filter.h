@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
             for (int r = 3; r < 15; r += 2) m = F::max2(F::max2(m, acc[qb][r]), acc[qb][r + 1]);
             m = F::max2(m, acc[qb][15]);
             hm[qb] = __ballot(m >= theta[qb]);
-            if (!inner) hm[qb] &= __ballot((bpx * 32u + 32u > ra[qb]) & (bpx * 32u < rb[qb]));
+            if (!inner) hm[qb] &= __ballot(bpx * 32u + 32u > ra[qb]) & __ballot(bpx * 32u < rb[qb]);  // (each compare IS a lane mask)
     #ifdef HVS_EXPERIMENT_NOHIT
             hm[qb] = __ballot(m == (typename F::thr_t)12345678);  // keeps the max chain alive, (almost) never true: ceiling experiment
     #endif
@@ -1295,8 +1295,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
             mask &= mask - 1u;
             more = __ballot(mask != 0u);
             const uint32_t pos = rowbase + (r & 3u) + 8u * (r >> 2);
-            const bool c = r < 16u && pos >= a && pos < b;
-            const uint64_t cm = __ballot(c);
+            const bool c = (r < 16u) & (pos >= a) & (pos < b);
+            const uint64_t cm = __ballot(r < 16u) & __ballot(pos >= a) & __ballot(pos < b);  // (the compares ARE lane masks)
             if (c) lbuf[wcnt + hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | pos;
             wcnt += (uint32_t)__popcll(cm);
             if (wcnt > 192u) flush();

@@ -132,7 +132,7 @@ int main(int argc, char** argv)
 #endif
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int blocks = LAB_OCC == 1 ? 1024 : 2048;
+    const int blocks = argc > 2 ? atoi(argv[2]) : (LAB_OCC == 1 ? 1024 : 2048);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL(lab, dim3(blocks), dim3(256), 0, 0, in, tiles, out, ntiles, 0x7fffff00);
