@@ -634,6 +634,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     const uint32_t qi = B.qid[s];
     uint32_t a = 0, b = 0;
     double qn = 0.0, e2 = 0.0, nb2 = 0.0;
+    bool clipped = false;
     if (qi != 0xFFFFFFFFu) {
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
         const HvsQParams p = hvs_parse_query(q);
@@ -647,6 +648,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
                 qn += x * x;
                 e2 += (x - xq) * (x - xq);
                 nb2 += xq * xq;
+                clipped = clipped || !(fabs(x * inv_sd) <= 127.5);
             }
         } else {
             for (int k = 0; k < HVS_NDIM; ++k) {
@@ -659,6 +661,10 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
         }
         if (count_pairs) atomicAdd(&counters[0], (unsigned long long)(b - a));
     }
+    // INT8 format: a query outside the data's bounding box is clipped and its band would let nearly every row
+    // through -- flooding the pair list of its whole group.  It is answered by the exact engine instead and takes
+    // no part in the filter (empty range).
+    if (clipped) a = b = 0u;
     B.ra[s] = a;
     B.rb[s] = b;
     B.qn[s] = qn;
@@ -668,7 +674,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     B.topcnt[s] = 0;
     B.candcnt[s] = 0;
     // a query with non-finite components has no usable bound: it is answered by the exact engine
-    B.overflow[s] = (qi != 0xFFFFFFFFu && !(qn < 1.0e30)) ? 1u : 0u;
+    B.overflow[s] = (qi != 0xFFFFFFFFu && (clipped || !(qn < 1.0e30))) ? 1u : 0u;
     B.tau[s] = __builtin_inff();
     // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
     if (fmt == HVS_FMT_I8)

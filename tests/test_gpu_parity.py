@@ -400,3 +400,55 @@ def test_data_sharded_mode_virtual_ranks(engine):
     ref, _ = T.oracle_query(nodes, queries)
     T.check_parity(nodes, queries, ids, ref, got_dists=dists)
     assert (parts[0][0] == 0xFFFFFFFF).any(), "some shard answers must be partial"
+
+
+def test_planner_picks_a_format_and_answers_stay_identical():
+    """HVS_ENGINE_AUTO: evenly filled data gets INT8 tiles, data whose quantisation band is hopeless
+    (one huge coordinate per row scale) does not; the answers are the oracle's either way."""
+    n, nq = 60_000, 200
+    nodes = T.gen_data(n, 71, T.GEN_V1, 10)
+    queries = T.gen_queries(nq, 72, T.GEN_V1, 10)
+    heavy = nodes.copy()
+    rng = np.random.default_rng(5)
+    heavy[:, 2:] = (rng.standard_normal((n, 100)) * np.exp(rng.standard_normal((n, 1)) * 2.5)).astype(np.float32)
+    hq = queries.copy()
+    hq[:, 4:] = (rng.standard_normal((nq, 100)) * np.exp(rng.standard_normal((nq, 1)) * 2.5)).astype(np.float32)
+    chosen = []
+    for d, q in ((nodes, queries), (heavy, hq)):
+        ref, _ = T.oracle_query(d, q)
+        with PKG.Engine(0) as e:
+            e.load_data(d)                       # engine AUTO
+            ids, dists = e.query(q, 1.0)
+            t = e.last_timing()
+            chosen.append(t.engine)
+            T.check_parity(d, q, ids, ref, got_dists=dists)
+            e.set_engine(PKG.ENGINE_MFMA_I8)     # forced INT8 on the same data: same bits, maybe via fallbacks
+            ids8, dists8 = e.query(q, 1.0)
+            assert np.array_equal(ids, ids8) and np.array_equal(dists.view(np.uint32), dists8.view(np.uint32))
+            print("auto engine", t.engine, "forced int8 fallback queries", e.last_timing().fallback_queries)
+    assert chosen[0] == PKG.ENGINE_MFMA_I8 and chosen[1] in FILTER_ENGINES
+
+
+@pytest.mark.parametrize("fengine", FILTER_ENGINES, ids=FILTER_IDS)
+def test_filter_engines_on_degenerate_value_ranges(fengine):
+    """All rows equal, vectors scaled to 1e-20 / 1e+15, queries far outside the data's bounding box: the bound
+    either holds or the engine steps aside (other format / exact engine); answers never change."""
+    base = T.gen_data(40_000, 81, T.GEN_V1, 5)
+    queries = T.gen_queries(96, 82, T.GEN_V1, 5)
+    cases = []
+    same = base.copy(); same[:, 2:] = same[0, 2:]
+    cases.append((same, queries))
+    for sc in (1e-20, 1e15):   # (squared distances still finite in f32)
+        d = base.copy(); d[:, 2:] *= np.float32(sc)
+        q = queries.copy(); q[:, 4:] *= np.float32(sc)
+        cases.append((d, q))
+    far = queries.copy(); far[::3, 4:] += 50.0; far[1::3, 4:] *= -40.0
+    cases.append((base, far))
+    for d, q in cases:
+        ref, _ = T.oracle_query(d, q)
+        with PKG.Engine(0) as e:
+            e.set_engine(fengine)
+            e.load_data(d)
+            ids, dists = e.query(q, 1.0)
+            print("engine ran:", e.last_timing().engine, "fallback", e.last_timing().fallback_queries)
+        T.check_parity(d, q, ids, ref, got_dists=dists)
