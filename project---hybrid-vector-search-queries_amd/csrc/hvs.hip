@@ -392,6 +392,9 @@ int build_index(hvs_ctx* c)
     const uint32_t n = c->n;
     const HvsLevels L = hvs_make_levels(n);
     if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
+    // survivor entries carry the block position in 22 bits: above 2^27 rows per GPU the exact engine answers
+    // (such a data set is sharded over GPUs anyway: 2^27 rows are 54.8 GB of rows + 35 GB of INT8 index)
+    if (L.nblk > HVS_ENTRY_MAX_BLOCKS) return HVS_OK;
     c->lv = L;
     int rc;
     uint64_t *k_ct = nullptr, *k_t = nullptr;

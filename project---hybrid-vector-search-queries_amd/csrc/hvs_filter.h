@@ -60,6 +60,9 @@
 #define HVS_FILTER_OCC 2      // waves per SIMD the filter kernel is compiled for
 #endif
 #define HVS_TOPCAP 128        // stored top list stride
+#ifndef HVS_RESCORE_UNROLL
+#define HVS_RESCORE_UNROLL 4   // groups of 8 pairs a re-scoring wave keeps in flight
+#endif
 
 typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float hvs_f32x16 __attribute__((ext_vector_type(16)));
@@ -500,10 +503,31 @@ struct HvsBatch {
     uint32_t* candcnt;          // [nslots]
     uint32_t* overflow;         // [nslots]
     // filter output
-    uint64_t* pairs;            // [ngroups][HVS_GCAP]  (slot << 32 | pos)
+    uint64_t* pairs;            // [ngroups][HVS_GCAP]  survivor entries (hvs_entry_make)
     uint32_t* paircnt;          // [ngroups]
     uint32_t* goverflow;        // [ngroups]
 };
+
+// Survivor entry of the filter (8 bytes in the group's pair list): the lanes of one (tile, query block) whose
+// accumulators reached the threshold.  bits 0..15 accumulator mask (bit r = row (r & 3) + 8 (r >> 2) + 4 half of
+// the block), 16..37 block position (22 bits: orderings of up to 2^27 rows), 38 row half, 39..63 slot.
+#define HVS_ENTRY_MAX_BLOCKS (1u << 22)
+#define HVS_ENTRY_MAX_SLOTS (1u << 25)
+__device__ __forceinline__ uint64_t hvs_entry_make(uint32_t slot, uint32_t bp, uint32_t half, uint32_t mask)
+{
+    const uint32_t lo = (bp << 16) | mask;
+    const uint32_t hi = (slot << 7) | (half << 6) | (bp >> 16);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t hvs_entry_slot(uint64_t e) { return (uint32_t)(e >> 39); }
+__device__ __forceinline__ uint32_t hvs_entry_mask(uint64_t e) { return (uint32_t)e & 0xFFFFu; }
+// position of row bit r of the entry
+__device__ __forceinline__ uint32_t hvs_entry_pos(uint64_t e, uint32_t r)
+{
+    const uint32_t bp = (uint32_t)(e >> 16) & (HVS_ENTRY_MAX_BLOCKS - 1u);
+    const uint32_t half = (uint32_t)(e >> 38) & 1u;
+    return bp * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+}
 
 // class rank of a query type: (C,T)-ordering classes first, the T-ordering class (type 2) last
 __device__ __forceinline__ uint32_t hvs_type_rank(uint32_t type)
@@ -1285,28 +1309,21 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     #endif
         }
     };
-    // Survivors of one query block (about one wave-tile in ten at the top level, every tile at the low ones).
-    // Kept SMALL on purpose: a fully unrolled scan (one compare + branch + append per accumulator, 64 copies)
-    // is ~30 KiB of code entered at a random place each time; here the block builds a per-lane bit mask of its
-    // 16 accumulators in straight-line code and one short loop extracts the set bits (usually one bit in one
-    // lane -> one trip).  The loop's exit test is issued right after the mask update, ahead of the append.
-    auto survivors = [&](int qb, uint32_t bpx) {
+    // Survivors of one query block (about one wave-tile in ten at the top level, every tile at the low ones --
+    // each level hands a query ~100 new candidates whatever its size).  The matrix waves do the minimum: a
+    // per-lane bit mask of the 16 accumulators (straight-line v_cmp + v_addc_co) and ONE compaction of the lanes
+    // with a non-zero mask into 8-byte SURVIVOR ENTRIES (hvs_entry_*): slot, block position, row half, mask.
+    // Turning entries into (slot, row position) pairs, the per-row range test and everything else happens in
+    // the re-scoring kernel, which waits on HBM anyway.
+    auto survivors = [&](int qb, uint32_t bpx, bool inner) {
         uint32_t mask = hvs_hit_mask(acc[qb], theta[qb]);
+        // (a lane still collecting its first 100 rows passes everything: keep it to the blocks of its own range)
+        if (!inner) mask = ((bpx * 32u + 32u > ra[qb]) & (bpx * 32u < rb[qb])) ? mask : 0u;
         const uint32_t slot = g * HVS_GROUP + qb * 32u + (lane & 31u);
-        const uint32_t a = ra[qb], b = rb[qb];
-        const uint32_t rowbase = bpx * 32u + 4u * (lane >> 5);
-        uint64_t more;
-        do {
-            const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this lane has nothing (left)
-            mask &= mask - 1u;
-            more = __ballot(mask != 0u);
-            const uint32_t pos = rowbase + (r & 3u) + 8u * (r >> 2);
-            const bool c = (r < 16u) & (pos >= a) & (pos < b);
-            const uint64_t cm = __ballot(r < 16u) & __ballot(pos >= a) & __ballot(pos < b);  // (the compares ARE lane masks)
-            if (c) lbuf[wcnt + hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | pos;
-            wcnt += (uint32_t)__popcll(cm);
-            if (wcnt > 192u) flush();
-        } while (more != 0ull);
+        const uint64_t nz = __ballot(mask != 0u);
+        if (mask != 0u) lbuf[wcnt + hvs_prefix_count(nz)] = hvs_entry_make(slot, bpx, lane >> 5, mask);
+        wcnt += (uint32_t)__popcll(nz);
+        if (wcnt > 192u) flush();
     };
     auto valid = [&](uint32_t i) { return active && i >= i0 && i < i1; };  // wave-uniform
 
@@ -1347,7 +1364,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         if (any != 0ull) {
     #pragma unroll
             for (int qb = 0; qb < HVS_QB; ++qb)
-                if (hm[qb] != 0ull) survivors(qb, bpx);
+                if (hm[qb] != 0ull) survivors(qb, bpx, inner);
         }
     };
     for (uint32_t st = 0; st < nstage; ++st) {
@@ -1380,14 +1397,17 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // ---------------------------------------------------------------------------------------------
 // hvs_k_rescore -- exact-order distances of the filter's survivors, key appended to the slot's list.
 //
-// EIGHT lanes per (slot,pos) pair, lane j playing AVX lane j of the reference (optimized_impl.h:96-125):
+// Front end (per wave, 64 survivor entries at a time, lane = entry): the k-th set bit of every entry's mask is
+// turned into a (slot, row position) pair, range-tested against the slot's own position range and packed into a
+// wave-private list in LDS; rounds repeat while any entry has bits left (usually one round).
+// Back end: EIGHT lanes per pair, lane j playing AVX lane j of the reference (optimized_impl.h:96-125):
 // it accumulates dims j, 8+j, ..., 88+j (and 92+j for j >= 4: the masked tail) in that order, then the
 // horizontal sum ((a0+a4)+(a1+a5))+((a2+a6)+(a3+a7)) runs across the 8 lanes (xor 4, xor 1, xor 2; f32
 // addition is commutative, so every lane ends with the same bits as the sequential hvs_exact_dist).
 // The point is the memory access: one load instruction of a wave reads 8 rows x 32 contiguous bytes, and the
 // four instructions that walk one 128-byte line follow each other directly.  (One lane per pair -- 64 rows
 // x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
-// re-fetched lines from L2/HBM many times: 43 ms per 381 M pairs.)
+// re-fetched lines from L2/HBM many times.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
                                                      HvsBatch B, const uint32_t* __restrict__ perm_ct,
@@ -1396,19 +1416,16 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
 {
     // the group's 128 query vectors are staged in LDS once per block (51 KB)
     __shared__ float sq[HVS_GROUP][HVS_NDIM];
+    __shared__ uint64_t slist[4][64];  // wave-private (slot << 32 | position) pairs of one round
     const uint32_t g = blockIdx.y;
     uint32_t np = B.paircnt[g];
-    // a group whose pair list overflowed holds unwritten entries past the failed flush: none of
-    // its pairs are used, all of its queries are re-run by the exact engine
+    // a group whose entry list overflowed holds unwritten entries past the failed flush: none of
+    // them are used, all of its queries are re-run by the exact engine
     if (np > HVS_GCAP || B.goverflow[g]) np = 0;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        atomicAdd(&counters[2], (unsigned long long)np);
-        if (B.goverflow[g]) {
-            for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
-        }
+    if (blockIdx.x == 0u && threadIdx.x == 0u && B.goverflow[g]) {
+        for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
     }
-    constexpr uint32_t kPairsPerBlock = 256u / 8u;
-    if (blockIdx.x * kPairsPerBlock >= np) return;  // uniform over the block
+    if (blockIdx.x * 256u >= np) return;  // uniform over the block
     for (uint32_t e = threadIdx.x; e < HVS_GROUP * (HVS_NDIM / 4); e += blockDim.x) {
         const uint32_t ql = e / (HVS_NDIM / 4), c4 = e % (HVS_NDIM / 4);
         const uint32_t qi = B.qid[g * HVS_GROUP + ql];
@@ -1418,45 +1435,85 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
     }
     __syncthreads();
     const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
-    const uint32_t j = threadIdx.x & 7u;
-    for (uint32_t base = blockIdx.x * kPairsPerBlock; base < np; base += gridDim.x * kPairsPerBlock) {  // uniform
-        const uint32_t e = base + (threadIdx.x >> 3);
-        const bool have = e < np;
-        const uint64_t pr = have ? B.pairs[(size_t)g * HVS_GCAP + e] : ((uint64_t)(g * HVS_GROUP) << 32);
-        const uint32_t slot = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
-        const uint32_t id = have ? perm[pos] : 0u;
-        // sampled prefix (sample_proportion < 1): the filter does not know about it
-        const bool ok = have && id < sn;
-        const float* __restrict__ dv = D + (size_t)(ok ? id : 0u) * HVS_DCOLS + 2;
-        const float* qv = &sq[slot - g * HVS_GROUP][0];
-        float dk[13];
-    #pragma unroll
-        for (int b = 0; b < 12; ++b) dk[b] = dv[8 * b + j];
-        dk[12] = dv[92u + (j | 4u)];
-        float acc = 0.0f;
-    #pragma unroll
-        for (int b = 0; b < 12; ++b) {
-            float t = dk[b] - qv[8 * b + j];
-            t = t * t;
-            acc = acc + t;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t j = lane & 7u;
+    uint64_t* list = slist[w];
+    uint32_t npairs = 0;  // wave-uniform
+    for (uint32_t base = (blockIdx.x * 4u + w) * 64u; base < np; base += gridDim.x * 256u) {  // wave-uniform
+        const uint32_t ei = base + lane;
+        const uint64_t ent = ei < np ? B.pairs[(size_t)g * HVS_GCAP + ei] : 0ull;  // (mask 0: nothing)
+        uint32_t mask = hvs_entry_mask(ent);
+        const uint32_t eslot = hvs_entry_slot(ent);
+        uint32_t ra = 0u, rb = 0u;
+        if (mask != 0u) {
+            ra = B.ra[eslot];
+            rb = B.rb[eslot];
         }
-        {
-            float t = dk[12] - qv[92u + (j | 4u)];
-            t = t * t;
-            const float with_tail = acc + t;
-            acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
-        }
-        const float s = acc + __shfl_xor(acc, 4);
-        const float a = s + __shfl_xor(s, 1);
-        const float dist = a + __shfl_xor(a, 2);
-        if (ok && j == 0u && dist <= B.tau[slot]) {
-            const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
-            if (k < HVS_FCAP)
-                B.cand[(size_t)slot * HVS_FCAP + k] = hvs_make_key(dist, id);
-            else
-                B.overflow[slot] = 1u;
+        while (__ballot(mask != 0u) != 0ull) {
+            const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this entry has nothing left
+            mask &= mask - 1u;
+            const uint32_t pos = hvs_entry_pos(ent, r);
+            const bool c = (r < 16u) & (pos >= ra) & (pos < rb);
+            const uint64_t cm = __ballot(c);
+            const uint32_t cnt = (uint32_t)__popcll(cm);
+            if (c) list[hvs_prefix_count(cm)] = ((uint64_t)eslot << 32) | pos;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            npairs += cnt;
+            // HVS_RESCORE_UNROLL groups of 8 pairs per pass: their row loads are all issued before the first
+            // use, so a wave keeps 32 rows in flight (the kernel is bound by HBM latency x rows in flight)
+            for (uint32_t p0 = 0; p0 < cnt; p0 += 8u * HVS_RESCORE_UNROLL) {  // wave-uniform
+                uint32_t slot[HVS_RESCORE_UNROLL], id[HVS_RESCORE_UNROLL];
+                bool ok[HVS_RESCORE_UNROLL];
+                float dk[HVS_RESCORE_UNROLL][13];
+    #pragma unroll
+                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                    const uint32_t pi = p0 + 8u * u + (lane >> 3);
+                    const bool have = pi < cnt;
+                    const uint64_t pr = list[have ? pi : 0u];
+                    slot[u] = (uint32_t)(pr >> 32);
+                    id[u] = have ? perm[(uint32_t)pr] : 0u;
+                    // sampled prefix (sample_proportion < 1): the filter does not know about it
+                    ok[u] = have && id[u] < sn;
+                }
+    #pragma unroll
+                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                    const float* __restrict__ dv = D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2;
+    #pragma unroll
+                    for (int b = 0; b < 12; ++b) dk[u][b] = dv[8 * b + j];
+                    dk[u][12] = dv[92u + (j | 4u)];
+                }
+    #pragma unroll
+                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                    const float* qv = &sq[slot[u] - g * HVS_GROUP][0];
+                    float acc = 0.0f;
+    #pragma unroll
+                    for (int b = 0; b < 12; ++b) {
+                        float t = dk[u][b] - qv[8 * b + j];
+                        t = t * t;
+                        acc = acc + t;
+                    }
+                    {
+                        float t = dk[u][12] - qv[92u + (j | 4u)];
+                        t = t * t;
+                        const float with_tail = acc + t;
+                        acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
+                    }
+                    const float sm = acc + __shfl_xor(acc, 4);
+                    const float am = sm + __shfl_xor(sm, 1);
+                    const float dist = am + __shfl_xor(am, 2);
+                    if (ok[u] && j == 0u && dist <= B.tau[slot[u]]) {
+                        const uint32_t k = atomicAdd(&B.candcnt[slot[u]], 1u);
+                        if (k < HVS_FCAP)
+                            B.cand[(size_t)slot[u] * HVS_FCAP + k] = hvs_make_key(dist, id[u]);
+                        else
+                            B.overflow[slot[u]] = 1u;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the list is rewritten by the next round
         }
     }
+    if (lane == 0u && npairs) atomicAdd(&counters[2], (unsigned long long)npairs);
 }
 
 // ---------------------------------------------------------------------------------------------
