@@ -620,8 +620,14 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
                            c->d_counters);
 
-    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_data, n, sn, c->d_q, B,
-                       c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters);
+    // level 0 by the exact kernel; small batches cut it into chunks so that enough waves are in flight
+    const uint32_t l0blocks = L.off[1] - L.off[0];
+    const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
+    uint32_t seed_chunks = 1u;
+    if (l0blocks <= HVS_FCAP / 32u && seed_waves < 2048u) seed_chunks = std::min(l0blocks, hvs_ceil_div(2048u, seed_waves));
+    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0, c->stream,
+                       c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
+                       std::max(1u, seed_chunks));
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                        c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
     // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on

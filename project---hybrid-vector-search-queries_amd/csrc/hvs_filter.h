@@ -807,8 +807,11 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
                                                            const uint32_t* __restrict__ perm_t,
                                                            const uint32_t* __restrict__ bpos_ct,
                                                            const uint32_t* __restrict__ bpos_t, HvsLevels L,
-                                                           unsigned long long* __restrict__ counters)
+                                                           unsigned long long* __restrict__ counters, uint32_t nchunks)
 {
+    // nchunks > 1 (small batches, level 0 of at most 1024 rows): grid.y waves share one 64-slot group, each
+    // takes every nchunks-th level-0 block and appends to the slots' lists with atomics -- a single wave per
+    // group walks ~1000 randomly placed rows one after the other and is latency-bound (2 ms at 10^4 queries)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t slot = w * 64u + lane;
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
     uint64_t* __restrict__ mylist = B.cand + (size_t)slot * HVS_FCAP;
     float tau = __builtin_inff();
     uint32_t cnt = 0, nscan = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
+    for (uint32_t i = lo + blockIdx.y; i < hi; i += nchunks) {
         const uint32_t b = bpos[i];
         for (uint32_t r = 0; r < 32u; ++r) {
             const uint32_t pos = b * 32u + r;
@@ -848,6 +851,16 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
             nscan += 64u;
             HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(D + (size_t)id * HVS_DCOLS + 2)};
             const float dist = hvs_exact_dist_pk(dv, q2);
+            if (nchunks > 1u) {  // wave-uniform
+                if (pass) {
+                    const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
+                    if (k < HVS_FCAP)
+                        mylist[k] = hvs_make_key(dist, id);
+                    else
+                        B.overflow[slot] = 1u;
+                }
+                continue;
+            }
             if (pass && dist <= tau) {
                 mylist[cnt] = hvs_make_key(dist, id);
                 ++cnt;
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
             }
         }
     }
-    B.candcnt[slot] = cnt;
+    if (nchunks == 1u) B.candcnt[slot] = cnt;
     if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nscan);
 }
 
