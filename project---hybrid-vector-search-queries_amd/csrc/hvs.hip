@@ -624,7 +624,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     const uint32_t l0blocks = L.off[1] - L.off[0];
     const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
     uint32_t seed_chunks = 1u;
-    if (l0blocks <= HVS_FCAP / 32u && seed_waves < 2048u) seed_chunks = std::min(l0blocks, hvs_ceil_div(2048u, seed_waves));
+    if (l0blocks <= HVS_FCAP / 32u && seed_waves < 16384u) seed_chunks = std::min(l0blocks, hvs_ceil_div(16384u, seed_waves));
     hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0, c->stream,
                        c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
                        std::max(1u, seed_chunks));
