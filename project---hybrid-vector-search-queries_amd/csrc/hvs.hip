@@ -97,6 +97,8 @@ uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi)
 // queries answered per pass over D; HVS_EXACT_BATCH / HVS_MFMA_BATCH override (tests use small batches)
 const uint32_t kBatch = env_u32("HVS_EXACT_BATCH", 65536u, 64u, 1u << 20);
 const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 262144u, 128u, 1u << 20);
+// re-scoring blocks per group (each stages the group's 128 queries in LDS): HVS_RESCORE_BLOCKS overrides
+const uint32_t kRescoreBlocks = env_u32("HVS_RESCORE_BLOCKS", 0u, 0u, 64u);  // 0: chosen per batch
 // exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
 const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
@@ -630,6 +632,10 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
                        std::max(1u, seed_chunks));
     hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                        c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+    // re-scoring blocks per group: each block stages the group's 128 queries in LDS first, so large batches use
+    // few long-lived blocks per group (2: -4 % of the step at 262144 queries) and small batches enough blocks to
+    // fill the chip
+    const uint32_t rescore_blocks = kRescoreBlocks ? kRescoreBlocks : std::max(2u, std::min(8u, hvs_ceil_div(4096u, B.ngroups)));
     // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on
     // D=1e6 x 1e4 queries: fewer launches but 3x the candidates per round -- slower, 0.93 vs 1.01 M q/s.)
     const uint32_t lstep = 1u;
@@ -652,7 +658,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
                 c->n_launch_events++;
             }
         }
-        hipLaunchKernelGGL(hvs_k_rescore, dim3(8, B.ngroups), dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
+        hipLaunchKernelGGL(hvs_k_rescore, dim3(rescore_blocks, B.ngroups), dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
         hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
                            c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);

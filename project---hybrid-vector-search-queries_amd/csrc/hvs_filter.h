@@ -1492,8 +1492,13 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
                 for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
                     const float* __restrict__ dv = D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2;
     #pragma unroll
+#ifdef HVS_EXPERIMENT_RESCORE_PARTIAL
+                    for (int b = 0; b < 12; ++b) dk[u][b] = b < HVS_EXPERIMENT_RESCORE_PARTIAL ? dv[8 * b + j] : 0.5f;  // timing experiment only
+                    dk[u][12] = 0.5f;
+#else
                     for (int b = 0; b < 12; ++b) dk[u][b] = dv[8 * b + j];
                     dk[u][12] = dv[92u + (j | 4u)];
+#endif
                 }
     #pragma unroll
                 for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
