@@ -60,6 +60,9 @@
 #define HVS_FILTER_OCC 2      // waves per SIMD the filter kernel is compiled for
 #endif
 #define HVS_TOPCAP 128        // stored top list stride
+#ifndef HVS_RESCORE_WAVES
+#define HVS_RESCORE_WAVES 8    // waves per re-scoring block (they share the group's queries in LDS)
+#endif
 #ifndef HVS_RESCORE_UNROLL
 #define HVS_RESCORE_UNROLL 4   // groups of 8 pairs a re-scoring wave keeps in flight
 #endif
@@ -1422,14 +1425,14 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
 // re-fetched lines from L2/HBM many times.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
+__global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
                                                      HvsBatch B, const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
                                                      unsigned long long* __restrict__ counters)
 {
     // the group's 128 query vectors are staged in LDS once per block (51 KB)
     __shared__ float sq[HVS_GROUP][HVS_NDIM];
-    __shared__ uint64_t slist[4][64];  // wave-private (slot << 32 | position) pairs of one round
+    __shared__ uint64_t slist[HVS_RESCORE_WAVES][64];  // wave-private (slot << 32 | position) pairs of one round
     const uint32_t g = blockIdx.y;
     uint32_t np = B.paircnt[g];
     // a group whose entry list overflowed holds unwritten entries past the failed flush: none of
@@ -1438,7 +1441,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
     if (blockIdx.x == 0u && threadIdx.x == 0u && B.goverflow[g]) {
         for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
     }
-    if (blockIdx.x * 256u >= np) return;  // uniform over the block
+    if (blockIdx.x * (64u * HVS_RESCORE_WAVES) >= np) return;  // uniform over the block
     for (uint32_t e = threadIdx.x; e < HVS_GROUP * (HVS_NDIM / 4); e += blockDim.x) {
         const uint32_t ql = e / (HVS_NDIM / 4), c4 = e % (HVS_NDIM / 4);
         const uint32_t qi = B.qid[g * HVS_GROUP + ql];
@@ -1452,7 +1455,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_rescore(const float* __restrict_
     const uint32_t j = lane & 7u;
     uint64_t* list = slist[w];
     uint32_t npairs = 0;  // wave-uniform
-    for (uint32_t base = (blockIdx.x * 4u + w) * 64u; base < np; base += gridDim.x * 256u) {  // wave-uniform
+    for (uint32_t base = (blockIdx.x * HVS_RESCORE_WAVES + w) * 64u; base < np; base += gridDim.x * (64u * HVS_RESCORE_WAVES)) {  // wave-uniform
         const uint32_t ei = base + lane;
         const uint64_t ent = ei < np ? B.pairs[(size_t)g * HVS_GCAP + ei] : 0ull;  // (mask 0: nothing)
         uint32_t mask = hvs_entry_mask(ent);
