@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
 // re-fetched lines from L2/HBM many times.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const float* __restrict__ D, uint32_t sn, const float* __restrict__ Q,
+__global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const float* __restrict__ D, uint32_t n, uint32_t sn, const float* __restrict__ Q,
                                                      HvsBatch B, const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
                                                      unsigned long long* __restrict__ counters)
@@ -1455,84 +1455,113 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     const uint32_t j = lane & 7u;
     uint64_t* list = slist[w];
     uint32_t npairs = 0;  // wave-uniform
-    for (uint32_t base = (blockIdx.x * HVS_RESCORE_WAVES + w) * 64u; base < np; base += gridDim.x * (64u * HVS_RESCORE_WAVES)) {  // wave-uniform
-        const uint32_t ei = base + lane;
-        const uint64_t ent = ei < np ? B.pairs[(size_t)g * HVS_GCAP + ei] : 0ull;  // (mask 0: nothing)
-        uint32_t mask = hvs_entry_mask(ent);
-        const uint32_t eslot = hvs_entry_slot(ent);
-        uint32_t ra = 0u, rb = 0u;
-        if (mask != 0u) {
-            ra = B.ra[eslot];
-            rb = B.rb[eslot];
-        }
-        while (__ballot(mask != 0u) != 0ull) {
-            const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);  // 16: this entry has nothing left
-            mask &= mask - 1u;
-            const uint32_t pos = hvs_entry_pos(ent, r);
-            const bool c = (r < 16u) & (pos >= ra) & (pos < rb);
-            const uint64_t cm = __ballot(c);
-            const uint32_t cnt = (uint32_t)__popcll(cm);
-            if (c) list[hvs_prefix_count(cm)] = ((uint64_t)eslot << 32) | pos;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            npairs += cnt;
-            // HVS_RESCORE_UNROLL groups of 8 pairs per pass: their row loads are all issued before the first
-            // use, so a wave keeps 32 rows in flight (the kernel is bound by HBM latency x rows in flight)
-            for (uint32_t p0 = 0; p0 < cnt; p0 += 8u * HVS_RESCORE_UNROLL) {  // wave-uniform
-                uint32_t slot[HVS_RESCORE_UNROLL], id[HVS_RESCORE_UNROLL];
-                bool ok[HVS_RESCORE_UNROLL];
-                float dk[HVS_RESCORE_UNROLL][13];
+
+    // exact distances of list[0..cnt) = (slot << 32 | row id).  HVS_RESCORE_UNROLL groups of 8 pairs per pass: their
+    // row loads are all issued before the first use, so a wave keeps 32 rows in flight
+    auto score_list = [&](uint32_t cnt) {
+        for (uint32_t p0 = 0; p0 < cnt; p0 += 8u * HVS_RESCORE_UNROLL) {  // wave-uniform
+            uint32_t slot[HVS_RESCORE_UNROLL], id[HVS_RESCORE_UNROLL];
+            bool ok[HVS_RESCORE_UNROLL];
+            float dk[HVS_RESCORE_UNROLL][13];
     #pragma unroll
-                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                    const uint32_t pi = p0 + 8u * u + (lane >> 3);
-                    const bool have = pi < cnt;
-                    const uint64_t pr = list[have ? pi : 0u];
-                    slot[u] = (uint32_t)(pr >> 32);
-                    id[u] = have ? perm[(uint32_t)pr] : 0u;
-                    // sampled prefix (sample_proportion < 1): the filter does not know about it
-                    ok[u] = have && id[u] < sn;
+            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                const uint32_t pi = p0 + 8u * u + (lane >> 3);
+                const uint64_t pr = list[pi < cnt ? pi : 0u];
+                slot[u] = (uint32_t)(pr >> 32);
+                id[u] = (uint32_t)pr;
+                // sampled prefix (sample_proportion < 1): the filter does not know about it
+                ok[u] = pi < cnt && id[u] < sn;
+            }
+    #pragma unroll
+            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                const float* __restrict__ dv = D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2;
+    #pragma unroll
+                for (int b = 0; b < 12; ++b) dk[u][b] = dv[8 * b + j];
+                dk[u][12] = dv[92u + (j | 4u)];
+            }
+    #pragma unroll
+            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
+                const float* qv = &sq[slot[u] - g * HVS_GROUP][0];
+                float acc = 0.0f;
+    #pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    float t = dk[u][b] - qv[8 * b + j];
+                    t = t * t;
+                    acc = acc + t;
                 }
-    #pragma unroll
-                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                    const float* __restrict__ dv = D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2;
-    #pragma unroll
-#ifdef HVS_EXPERIMENT_RESCORE_PARTIAL
-                    for (int b = 0; b < 12; ++b) dk[u][b] = b < HVS_EXPERIMENT_RESCORE_PARTIAL ? dv[8 * b + j] : 0.5f;  // timing experiment only
-                    dk[u][12] = 0.5f;
-#else
-                    for (int b = 0; b < 12; ++b) dk[u][b] = dv[8 * b + j];
-                    dk[u][12] = dv[92u + (j | 4u)];
-#endif
+                {
+                    float t = dk[u][12] - qv[92u + (j | 4u)];
+                    t = t * t;
+                    const float with_tail = acc + t;
+                    acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
                 }
-    #pragma unroll
-                for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                    const float* qv = &sq[slot[u] - g * HVS_GROUP][0];
-                    float acc = 0.0f;
-    #pragma unroll
-                    for (int b = 0; b < 12; ++b) {
-                        float t = dk[u][b] - qv[8 * b + j];
-                        t = t * t;
-                        acc = acc + t;
-                    }
-                    {
-                        float t = dk[u][12] - qv[92u + (j | 4u)];
-                        t = t * t;
-                        const float with_tail = acc + t;
-                        acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
-                    }
-                    const float sm = acc + __shfl_xor(acc, 4);
-                    const float am = sm + __shfl_xor(sm, 1);
-                    const float dist = am + __shfl_xor(am, 2);
-                    if (ok[u] && j == 0u && dist <= B.tau[slot[u]]) {
-                        const uint32_t k = atomicAdd(&B.candcnt[slot[u]], 1u);
-                        if (k < HVS_FCAP)
-                            B.cand[(size_t)slot[u] * HVS_FCAP + k] = hvs_make_key(dist, id[u]);
-                        else
-                            B.overflow[slot[u]] = 1u;
-                    }
+                const float sm = acc + __shfl_xor(acc, 4);
+                const float am = sm + __shfl_xor(sm, 1);
+                const float dist = am + __shfl_xor(am, 2);
+                if (ok[u] && j == 0u && dist <= B.tau[slot[u]]) {
+                    const uint32_t k = atomicAdd(&B.candcnt[slot[u]], 1u);
+                    if (k < HVS_FCAP)
+                        B.cand[(size_t)slot[u] * HVS_FCAP + k] = hvs_make_key(dist, id[u]);
+                    else
+                        B.overflow[slot[u]] = 1u;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the list is rewritten by the next round
         }
+    };
+    // one round: the lanes with `c` put (slot, id) into the wave's list, then the list is scored
+    auto round = [&](bool c, uint32_t slot, uint32_t id) {
+        const uint64_t cm = __ballot(c);
+        const uint32_t cnt = (uint32_t)__popcll(cm);
+        if (c) list[hvs_prefix_count(cm)] = ((uint64_t)slot << 32) | id;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        npairs += cnt;
+        score_list(cnt);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the list is rewritten by the next round
+    };
+    // Software pipeline over chunks of 64 entries (lane = entry): the entry of chunk c+2 and, for chunk c+1, the
+    // slot's range and the row id of its FIRST set bit (a dependent random load: entry -> perm[pos]) are fetched
+    // while chunk c is scored, so that the chain entry -> row id -> row is not paid serially per chunk.
+    const uint32_t stride = gridDim.x * (64u * HVS_RESCORE_WAVES);
+    const uint32_t first = (blockIdx.x * HVS_RESCORE_WAVES + w) * 64u;
+    auto load_entry = [&](uint32_t base) -> uint64_t {
+        const uint32_t ei = base + lane;
+        return (base < np && ei < np) ? B.pairs[(size_t)g * HVS_GCAP + ei] : 0ull;  // (mask 0: nothing)
+    };
+    struct Staged {
+        uint64_t ent;
+        uint32_t ra, rb, pos0, id0;
+    };
+    auto stage = [&](uint64_t ent) -> Staged {
+        Staged t;
+        t.ent = ent;
+        t.ra = t.rb = t.id0 = 0u;
+        const uint32_t m = hvs_entry_mask(ent);
+        t.pos0 = hvs_entry_pos(ent, (uint32_t)__builtin_ctz(m | 0x10000u) & 15u);
+        if (m != 0u) {
+            const uint32_t es = hvs_entry_slot(ent);
+            t.ra = B.ra[es];
+            t.rb = B.rb[es];
+            t.id0 = t.pos0 < n ? perm[t.pos0] : 0u;  // (bits of padding rows past the end of the ordering)
+        }
+        return t;
+    };
+    Staged cur = stage(load_entry(first));
+    uint64_t ent_next = load_entry(first + stride);
+    for (uint32_t base = first; base < np; base += stride) {  // wave-uniform
+        const Staged nxt = stage(ent_next);                    // loads in flight while `cur` is scored
+        ent_next = load_entry(base + 2u * stride);
+        const uint32_t eslot = hvs_entry_slot(cur.ent);
+        uint32_t mask = hvs_entry_mask(cur.ent);
+        round((mask != 0u) & (cur.pos0 >= cur.ra) & (cur.pos0 < cur.rb), eslot, cur.id0);
+        mask &= mask - 1u;
+        while (__ballot(mask != 0u) != 0ull) {  // entries with more than one bit (few)
+            const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);
+            mask &= mask - 1u;
+            const uint32_t pos = hvs_entry_pos(cur.ent, r & 15u);
+            const bool c = (r < 16u) & (pos >= cur.ra) & (pos < cur.rb);
+            round(c, eslot, c ? perm[pos] : 0u);
+        }
+        cur = nxt;
     }
     if (lane == 0u && npairs) atomicAdd(&counters[2], (unsigned long long)npairs);
 }
