@@ -183,7 +183,27 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
     uint64_t prefix = 0;
     uint32_t r = KEEP;
     uint32_t rem = cnt;  // keys that still match the decided prefix bits
-    for (int bit = 63; bit >= 0; --bit) {
+    // Bits above the highest bit in which any two keys differ are common to all keys (distances of one query's
+    // candidates share sign, exponent and often the first mantissa bits): they go into the prefix without a
+    // counting step each.
+    int top = 63;
+    {
+        const uint64_t k0 = list[0];  // cnt > KEEP >= 1: a valid key
+        uint64_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d |= valid[i] ? (k[i] ^ k0) : 0ull;
+        uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dlo |= (uint32_t)__shfl_xor((int)dlo, o);
+            dhi |= (uint32_t)__shfl_xor((int)dhi, o);
+        }
+        d = ((uint64_t)dhi << 32) | dlo;
+        d = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d);
+        top = d ? 63 - (int)__builtin_clzll(d) : 0;  // (d == 0 cannot happen: keys are distinct and cnt > 1)
+        prefix = top < 63 ? (k0 & (~0ull << (top + 1))) : 0ull;
+    }
+    for (int bit = top; bit >= 0; --bit) {
         const uint64_t himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
         uint32_t c0 = 0;
 #pragma unroll
