@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=10_000_000, help="rows of D")
-    ap.add_argument("--batch", type=int, default=262144, help="queries per step per GPU")
+    ap.add_argument("--batch", type=int, default=1048576, help="queries per step per GPU")
     ap.add_argument("--force-type", type=int, default=-1, help="-1 mixed types, 0..3 a single type")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--engine", type=int, default=0)

@@ -96,7 +96,7 @@ uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi)
 }
 // queries answered per pass over D; HVS_EXACT_BATCH / HVS_MFMA_BATCH override (tests use small batches)
 const uint32_t kBatch = env_u32("HVS_EXACT_BATCH", 65536u, 64u, 1u << 20);
-const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 262144u, 128u, 1u << 20);
+const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 1u << 20, 128u, 1u << 20);
 // re-scoring blocks per group (each stages the group's 128 queries in LDS): HVS_RESCORE_BLOCKS overrides
 const uint32_t kRescoreBlocks = env_u32("HVS_RESCORE_BLOCKS", 0u, 0u, 64u);  // 0: chosen per batch
 // exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
