@@ -5,7 +5,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
 
 Workload (BASELINE.json metric: queries/sec + recall@100 on D=10^7, Q=4x10^6, dim=100, k=100):
-D = 10^7 gen-v1 rows replicated in every GPU's HBM; the 4x10^6-query set is streamed in batches;
+D = 10^7 gen-v1 rows replicated in every GPU's HBM; the 4x10^6-query set is streamed in batches (2^20 by default:
+warmup + 3 steps = the whole query set);
 one STEP = one pass of the hot path over one batch of `--batch` mixed-type queries per GPU
 (inputs resident in HBM when the timed region starts, result ids gathered to rank 0 over RCCL
 inside the timed region when N > 1).  Queries shard across ranks with no data-path collective
