@@ -117,6 +117,16 @@ int hvs_download_results(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *out_i
 /* Copy result rows [q0,q0+nq) into caller-owned DEVICE buffers (same GPU), e.g. a collective's
  * send buffer.  d_dists may be NULL.  Asynchronous on the context stream. */
 int hvs_export_results_device(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *d_ids, float *d_dists);
+/* D-sharded mode (rows partitioned over GPUs, every GPU answers all queries on its rows with hvs_set_padding(ctx, 0)):
+ * merges the shards' partial answers on the device -- the multi-GPU counterpart of Knn::merge (reference
+ * include/optimized_impl.h:337-385) -- and applies the reference's padding (optimized_parallel.hpp:149-157) once.
+ * d_ids_all / d_dists_all: DEVICE, [nshards][nq][100] as an all_gather of the per-shard results lays them out (ids
+ * shard-local, 0xFFFFFFFF = empty slot); shard_row0: HOST, first global row of each shard (nshards <= 16);
+ * d_pad_dists: DEVICE, [nq][100], exact-order distance of query q to row n_total-1-s; outputs: DEVICE, [nq][100], global
+ * ids in ascending (dist, id) order (d_out_dists may be NULL).  Asynchronous on the context stream. */
+int hvs_merge_shards_device(hvs_ctx *ctx, uint32_t nshards, uint32_t nq, const uint32_t *d_ids_all,
+                            const float *d_dists_all, const uint64_t *shard_row0, uint32_t n_total,
+                            const float *d_pad_dists, uint32_t *d_out_ids, float *d_out_dists);
 /* Timing of the last hvs_query / hvs_query_resident (call after hvs_sync). */
 int hvs_last_timing(hvs_ctx *ctx, hvs_timing *out);
 

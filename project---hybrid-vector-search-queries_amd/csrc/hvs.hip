@@ -1032,6 +1032,27 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
     return hvs_download_results(c, 0, nq, out_ids, out_dists);
 }
 
+int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uint32_t* d_ids_all, const float* d_dists_all,
+                            const uint64_t* shard_row0, uint32_t n_total, const float* d_pad_dists, uint32_t* d_out_ids,
+                            float* d_out_dists)
+{
+    if (!c) return HVS_EINVAL;
+    if (!d_ids_all || !d_dists_all || !shard_row0 || !d_pad_dists || !d_out_ids || nshards == 0u || nshards > 16u ||
+        n_total < HVS_KNN)
+        return fail(c, HVS_EINVAL, "hvs_merge_shards_device: bad argument (1..16 shards, n_total >= 100, non-NULL buffers)");
+    if (nq == 0u) return HVS_OK;
+    HVS_HIP(c, hipSetDevice(c->device));
+    HvsShardRows rows{};
+    for (uint32_t s = 0; s < nshards; ++s) {
+        if (shard_row0[s] >= n_total) return fail(c, HVS_EINVAL, "hvs_merge_shards_device: shard row offset outside the data set");
+        rows.row0[s] = shard_row0[s];
+    }
+    hipLaunchKernelGGL(hvs_k_merge_shards, dim3((nq + 3u) / 4u), dim3(256), 0, c->stream, d_ids_all, d_dists_all, nshards, nq, rows,
+                       n_total, d_pad_dists, d_out_ids, d_out_dists);
+    HVS_HIP(c, hipGetLastError());
+    return HVS_OK;
+}
+
 int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
 {
     if (!c || !out) return HVS_EINVAL;

@@ -392,3 +392,71 @@ __global__ __launch_bounds__(256) void hvs_k_select(
         if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// hvs_k_merge_shards -- D-sharded mode: the multi-GPU counterpart of Knn::merge
+// (optimized_impl.h:337-385).  Every shard (GPU) answered ALL queries on its own rows with padding off:
+// ids are shard-local (0xFFFFFFFF = empty slot), lists sorted by (dist, id).  Per query (one wave): the
+// nshards x 100 keys (dist bits << 32 | global id) are reduced to the 100 smallest; when fewer than 100 rows
+// matched anywhere, rows n_total-1, n_total-2, ... are appended with their exact-order distances
+// (optimized_parallel.hpp:149-157; `pad_dists[q][s]` = distance of query q to row n_total-1-s), and the 100
+// keys leave in ascending (dist, id) order.  ids_all / dists_all: [nshards][nq][100] as all_gather lays them out.
+// ---------------------------------------------------------------------------------------------
+struct HvsShardRows {
+    uint64_t row0[16];  // first global row of each shard
+};
+
+__global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __restrict__ ids_all,
+                                                          const float* __restrict__ dists_all, uint32_t nshards,
+                                                          uint32_t nq, HvsShardRows rows, uint32_t n_total,
+                                                          const float* __restrict__ pad_dists,
+                                                          uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+{
+    __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4u + w;
+    if (q >= nq) return;  // wave-uniform
+    uint64_t* buf = sbuf[w];
+    uint32_t cnt = 0;
+    for (uint32_t s = 0; s < nshards; ++s) {
+        const size_t base = ((size_t)s * nq + q) * HVS_KNN;
+        for (uint32_t off = 0; off < HVS_KNN; off += 64u) {
+            if (cnt + 64u > HVS_CAND_CAP) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+                cnt = HVS_KNN;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            const uint32_t e = off + lane;
+            const uint32_t id = e < HVS_KNN ? ids_all[base + e] : 0xFFFFFFFFu;
+            const bool have = id != 0xFFFFFFFFu;
+            const uint64_t m = __ballot(have);
+            if (have) buf[cnt + hvs_prefix_count(m)] = hvs_make_key(dists_all[base + e], (uint32_t)(rows.row0[s] + id));
+            cnt += (uint32_t)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (cnt > HVS_KNN) {
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        cnt = HVS_KNN;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    for (uint32_t b = cnt; b < HVS_KNN; b += 64u) {
+        const uint32_t e = b + lane;
+        if (e < HVS_KNN) buf[e] = hvs_make_key(pad_dists[(size_t)q * HVS_KNN + (e - cnt)], n_total - 1u - (e - cnt));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // rank sort of exactly 100 keys (duplicates possible after padding: ties broken by slot)
+    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+        const uint64_t ke = buf[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+            const uint64_t kj = buf[j];
+            rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
+        }
+        out_ids[(size_t)q * HVS_KNN + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)q * HVS_KNN + rank] = hvs_key_dist(ke);
+    }
+}
+

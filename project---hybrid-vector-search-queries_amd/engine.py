@@ -121,6 +121,7 @@ def library():
         "hvs_sync": (C.c_int, [vp]),
         "hvs_download_results": (C.c_int, [vp, C.c_uint32, C.c_uint32, _u32p, _f32p]),
         "hvs_export_results_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+        "hvs_merge_shards_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, vp, vp]),
         "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
         "hvs_version": (C.c_char_p, []),
     }
@@ -237,6 +238,16 @@ class Engine:
         """Copy results into device buffers given as raw pointers (e.g. torch tensor.data_ptr())."""
         self._ck(self._lib.hvs_export_results_device(self._h, q0, nq, C.c_void_p(ids_ptr),
                                                      C.c_void_p(dists_ptr) if dists_ptr else None))
+
+    def merge_shards_device(self, ids_all_ptr, dists_all_ptr, shard_row0, nq, n_total, pad_dists_ptr, out_ids_ptr,
+                            out_dists_ptr=None):
+        """D-sharded mode: merge [nshards][nq][100] partial answers (device pointers, e.g. the output of an
+        all_gather) into the whole-set answer on the device; see hvs_merge_shards_device in include/hvs.h."""
+        rows = (C.c_uint64 * len(shard_row0))(*[int(r) for r in shard_row0])
+        self._ck(self._lib.hvs_merge_shards_device(self._h, len(shard_row0), nq, C.c_void_p(ids_all_ptr),
+                                                   C.c_void_p(dists_all_ptr), rows, n_total, C.c_void_p(pad_dists_ptr),
+                                                   C.c_void_p(out_ids_ptr),
+                                                   C.c_void_p(out_dists_ptr) if out_dists_ptr else None))
 
     def last_timing(self):
         t = Timing()

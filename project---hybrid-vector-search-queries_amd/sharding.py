@@ -105,9 +105,11 @@ def tail_pad_dists(answer_tail, queries):
     return out
 
 
-def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None, device="cpu"):
+def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None, device="cpu", engine=None):
     """Every rank: ids/dists of ALL queries on its row shard (padding off).  All ranks return the merged
-    global answer.  `pad_dists` must be the same on every rank (broadcast it from the tail's owner)."""
+    global answer.  `pad_dists` must be the same on every rank (broadcast it from the tail's owner).
+    With `engine` (an Engine on this rank's GPU, tensors on that GPU) the gathered lists are merged by the
+    device kernel (hvs_merge_shards_device); otherwise on the host (merge_data_shards)."""
     import torch
     import torch.distributed as dist
 
@@ -124,6 +126,15 @@ def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None
     dist.all_gather_into_tensor(ids_all, ids_t, group=group)
     dist.all_gather_into_tensor(d_all, d_t, group=group)
     dist.all_gather_into_tensor(r0_all, r0_t, group=group)
+    if engine is not None:
+        pad_t = torch.from_numpy(np.ascontiguousarray(pad_dists, np.float32)).to(device)
+        out_i = torch.empty((nq, 100), dtype=torch.int32, device=device)
+        out_d = torch.empty((nq, 100), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+        engine.merge_shards_device(ids_all.data_ptr(), d_all.data_ptr(), [int(r) for r in r0_all.cpu()], nq, n_total,
+                                   pad_t.data_ptr(), out_i.data_ptr(), out_d.data_ptr())
+        engine.sync()
+        return out_i.cpu().numpy().view(np.uint32), out_d.cpu().numpy()
     ids_all = ids_all.view(world, nq, -1)
     d_all = d_all.view(world, nq, -1)
     parts = [(ids_all[r].cpu().numpy().view(np.uint32), d_all[r].cpu().numpy(), int(r0_all[r])) for r in range(world)]

@@ -402,6 +402,56 @@ def test_data_sharded_mode_virtual_ranks(engine):
     assert (parts[0][0] == 0xFFFFFFFF).any(), "some shard answers must be partial"
 
 
+def test_data_sharded_device_merge_matches_host_merge():
+    """hvs_merge_shards_device (the GPU analogue of Knn::merge for row shards) on the layout an all_gather
+    produces, [shard][query][100], against sharding.merge_data_shards.  Runs in a subprocess that imports torch
+    BEFORE the library (one HIP runtime per process, as bench.py does)."""
+    import subprocess
+    import sys
+    code = r"""
+import importlib, sys, numpy as np, torch
+torch.cuda.init()
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import hvs_testlib as T
+PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
+sharding = importlib.import_module('project---hybrid-vector-search-queries_amd.sharding')
+n, nq, world = 150_000, 300, 3
+nodes = T.gen_data(n, 41, T.GEN_V1, 40); queries = T.gen_queries(nq, 42, T.GEN_V1, 40)
+queries[0, :4] = [3, 7, 0.5, 0.5001]; queries[1, :4] = [1, 999, -1, -1]
+parts = []
+for r in range(world):
+    r0, r1 = sharding.row_shard_range(n, r, world)
+    with PKG.Engine(0) as e:
+        e.set_padding(False); e.load_data(nodes[r0:r1])
+        ids, dists = e.query(queries, 1.0)
+    parts.append((ids, dists, r0))
+with PKG.Engine(0) as e:
+    e.load_data(nodes[n - 100:])
+    pad = sharding.tail_pad_dists(lambda q: e.query(q, 1.0), queries)
+ids, dists = sharding.merge_data_shards(parts, n, pad)
+ids_all = torch.from_numpy(np.stack([p[0] for p in parts]).view(np.int32)).cuda()
+d_all = torch.from_numpy(np.stack([p[1] for p in parts])).cuda()
+pad_t = torch.from_numpy(np.ascontiguousarray(pad, np.float32)).cuda()
+out_i = torch.empty((nq, 100), dtype=torch.int32, device='cuda'); out_d = torch.empty((nq, 100), dtype=torch.float32, device='cuda')
+torch.cuda.synchronize()
+with PKG.Engine(0) as e:
+    e.merge_shards_device(ids_all.data_ptr(), d_all.data_ptr(), [p[2] for p in parts], nq, n, pad_t.data_ptr(), out_i.data_ptr(), out_d.data_ptr())
+    e.sync()
+    assert np.array_equal(out_i.cpu().numpy().view(np.uint32), ids)
+    assert np.array_equal(out_d.cpu().numpy().view(np.uint32), dists.view(np.uint32))
+    try:
+        e.merge_shards_device(ids_all.data_ptr(), d_all.data_ptr(), [0] * 17, nq, n, pad_t.data_ptr(), out_i.data_ptr())
+        raise SystemExit('17 shards must be rejected')
+    except PKG.HvsError:
+        pass
+ref, _ = T.oracle_query(nodes, queries)
+T.check_parity(nodes, queries, out_i.cpu().numpy().view(np.uint32), ref, got_dists=out_d.cpu().numpy())
+print('SUBPROCESS-OK')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=T.REPO)
+    assert "SUBPROCESS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_planner_picks_a_format_and_answers_stay_identical():
     """HVS_ENGINE_AUTO: evenly filled data gets INT8 tiles, data whose quantisation band is hopeless
     (one huge coordinate per row scale) does not; the answers are the oracle's either way."""
