@@ -63,7 +63,7 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
-        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+        os.environ["NCCL_DEBUG"] = "NONE"  # RCCL logs (version banner, WARN lines) go to stdout: rank 0 prints ONE JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -91,11 +91,14 @@ def main():
     gathered = torch.empty((world * a.batch, K), dtype=torch.int32, device="cuda") if use_dist else None
 
     def step(b):
-        eng.query_resident(b * a.batch, a.batch, 1.0)
+        eng.query_resident(b * a.batch, a.batch, 1.0)                  # asynchronous on the library's stream
         if use_dist:
+            # the previous step's gather (RCCL's stream) ran under this step's compute; it must be done before
+            # its send buffer is overwritten
+            torch.cuda.current_stream().synchronize()
             eng.export_results_device(b * a.batch, a.batch, ids_dev.data_ptr())
             eng.sync()
-            dist.all_gather_into_tensor(gathered, ids_dev)             # result gather over xGMI (RCCL)
+            dist.all_gather_into_tensor(gathered, ids_dev)             # result gather over xGMI (RCCL), asynchronous
         else:
             eng.sync()
 
