@@ -341,7 +341,7 @@ int build_tiles(hvs_ctx* c, int fmt)
     int rc;
     c->tile_fmt = HVS_FMT_NONE;
     c->have_index = false;
-    // free first: the two formats never coexist (D = 1e8: 44.8 GB of BF16 tiles, 26.4 GB of INT8 tiles)
+    // free first: the two formats never coexist (D = 1e8: 44.8 GB of BF16 tiles, 20.8 GB of INT8 tiles)
     if ((rc = dev_alloc(c, &c->d_tiles_ct, (size_t)0))) return rc;
     if ((rc = dev_alloc(c, &c->d_tiles_t, (size_t)0))) return rc;
     if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)0))) return rc;

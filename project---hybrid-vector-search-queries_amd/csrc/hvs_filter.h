@@ -76,9 +76,11 @@ typedef int hvs_i32x16 __attribute__((ext_vector_type(16)));
 #define HVS_FMT_NONE 0
 #define HVS_FMT_BF16 1
 #define HVS_FMT_I8 2
-#define HVS_I8_KSTEPS 4        // 4 k-steps of 32 (K padded 100 -> 128)
-#define HVS_I8_TILE_U4 (HVS_I8_KSTEPS * 64)  // uint4 per 32-row INT8 tile (4 KiB)
-#define HVS_I8_NRM_U4 8        // uint4 per tile of per-row accumulator inits (32 x int32)
+#define HVS_I8_KSTEPS 4        // 4 MFMA k-steps of 32 (K padded 100 -> 128)
+#define HVS_I8_KMEM 3          // k-steps stored as full fragments (dims 0..95); the 4th holds 4 real dimensions
+#define HVS_I8_TILE_U4 (HVS_I8_KMEM * 64)  // uint4 per 32-row INT8 tile (3 KiB)
+#define HVS_I8_NRM_U4 16       // uint4 of side data per tile: [0,8) dims 96..99 of the 32 rows (4 x int8 each),
+                               // [8,16) the rows' accumulator inits (32 x int32)
 #define HVS_I8_PAD_NORM (-(1 << 30))  // accumulator init of a padding row: can never reach a threshold
 
 // ---------------------------------------------------------------------------------------------
@@ -328,8 +330,8 @@ __device__ __forceinline__ int hvs_quant_i8(double x, double inv_sd)
     return (r == r) ? (int)r : 0;
 }
 
-// one wave per storage block: 4 KiB INT8 A-operand tile (lane l of k-step s: row l&31, k = 32 s + 16 (l>>5) + 0..15),
-// the 32 accumulator inits and the row bounds
+// one wave per storage block: 3 KiB INT8 A-operand tile (lane l of k-step s: row l&31, k = 32 s + 16 (l>>5) + 0..15;
+// k-steps 0..2), 256 B of side data (dims 96..99 and the 32 accumulator inits) and the row bounds
 __global__ __launch_bounds__(256) void hvs_k_build_tiles_i8(const float* __restrict__ D, uint32_t n,
                                                             const uint32_t* __restrict__ perm, HvsLevels L,
                                                             const HvsQuant* __restrict__ qz, uint4* __restrict__ tiles,
@@ -361,10 +363,19 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles_i8(const float* __restr
             hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30));
             hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd) * (1.0 + 1e-9) + 1e-30));
         }
-        norms[(size_t)idx * 32u + r] = nh;
+        // side data: the 4 real dimensions of the 4th k-step (the other 28 are zero padding and are not stored:
+        // the filter rebuilds the fragment from this word), then the accumulator init
+        uint32_t tail = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = valid ? hvs_quant_i8((double)row[96 + e] - (double)qz->center[96 + e], inv_sd) : 0;
+            tail |= ((uint32_t)v & 0xFFu) << (8 * e);
+        }
+        norms[(size_t)idx * 64u + r] = (int)tail;
+        norms[(size_t)idx * 64u + 32u + r] = nh;
     }
 #pragma unroll
-    for (int s = 0; s < HVS_I8_KSTEPS; ++s) {
+    for (int s = 0; s < HVS_I8_KMEM; ++s) {
         uint32_t w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles_i8(const float* __restr
             }
             w[p] = word;
         }
-        tiles[((size_t)idx * HVS_I8_KSTEPS + s) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        tiles[((size_t)idx * HVS_I8_KMEM + s) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -1101,6 +1112,7 @@ struct HvsFmt;
 template <>
 struct HvsFmt<HVS_FMT_BF16> {
     static constexpr int KSTEPS = HVS_KSTEPS;
+    static constexpr int KMEM = HVS_KSTEPS;  // k-steps stored in the tile
     typedef hvs_bf16x8 frag_t;
     typedef hvs_f32x16 acc_t;
     typedef float thr_t;
@@ -1114,6 +1126,7 @@ struct HvsFmt<HVS_FMT_BF16> {
 template <>
 struct HvsFmt<HVS_FMT_I8> {
     static constexpr int KSTEPS = HVS_I8_KSTEPS;
+    static constexpr int KMEM = HVS_I8_KMEM;
     typedef hvs_i32x4 frag_t;
     typedef hvs_i32x16 acc_t;
     typedef int thr_t;
@@ -1137,7 +1150,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 {
     typedef HvsFmt<FMT> F;
     constexpr int KS = F::KSTEPS;
-    constexpr int TILE_U4 = KS * 64;
+    constexpr int KM = F::KMEM;  // k-steps held by the tile in memory (INT8: 3 of the 4)
+    constexpr int TILE_U4 = KM * 64;
     constexpr bool kI8 = FMT == HVS_FMT_I8;
     constexpr int STG = kI8 ? HVS_STAGE_I8 : HVS_STAGE;  // tiles per LDS stage
     // two stages of 4 A tiles shared by the 4 waves (BF16: 2 x 28 KiB, INT8: 2 x 16 KiB + the rows' accumulator inits)
@@ -1231,15 +1245,15 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // waited for its own chunks before any wave passes the barrier) and frees the current buffer
     // (every wave has finished its ds_reads of it).  One barrier per 4 tiles keeps the waves loosely coupled: a
     // wave that spends time on survivors of one tile catches up inside the stage.
-    constexpr int kChunksPerWave = (STG * KS + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
+    constexpr int kChunksPerWave = (STG * KM + HVS_WG_WAVES - 1) / HVS_WG_WAVES;
     auto issue_chunks = [&](uint32_t buf, uint32_t first_tile, int k0, int k1) {
         for (int k = k0; k < k1; ++k) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(wv) + (uint32_t)HVS_WG_WAVES * (uint32_t)k;  // chunk of the stage
-            if (c >= STG * KS) break;
-            uint32_t tile = first_tile + c / KS;
+            if (c >= STG * KM) break;
+            uint32_t tile = first_tile + c / KM;
             if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
-            const uint4* src = tiles + (size_t)tile * TILE_U4 + (c % KS) * 64u + lane;
-            const uint4* dst = &stile[buf][(c / KS) * TILE_U4 + (c % KS) * 64u];
+            const uint4* src = tiles + (size_t)tile * TILE_U4 + (c % KM) * 64u + lane;
+            const uint4* dst = &stile[buf][(c / KM) * TILE_U4 + (c % KM) * 64u];
             // LDS byte address of the chunk (wave-uniform) goes to M0; the instruction adds lane*16.
             // Issued as inline asm on purpose: hipcc orders every later ds_read behind a
             // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise the prefetch
@@ -1256,15 +1270,19 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
         issue_chunks(buf, first_tile, 0, kChunksPerWave);
         if constexpr (kI8) {
-            // the stage's accumulator inits (4 tiles x 32 x int32 = 512 B, contiguous in storage order): one
-            // half-wave LDS-DMA by the last wave
-            if (__builtin_amdgcn_readfirstlane(wv) == HVS_WG_WAVES - 1u) {
-                uint32_t tile = first_tile + (lane >> 3);
+            // the stage's side data (per tile 128 B of tail dimensions + 128 B of accumulator inits, contiguous in
+            // storage order): STG * 16 uint4, 64 per wave-instruction, issued by the last waves
+            constexpr uint32_t kAuxInstr = (STG * HVS_I8_NRM_U4 + 63u) / 64u;
+            const uint32_t wvs = __builtin_amdgcn_readfirstlane(wv);
+            if (wvs + kAuxInstr >= HVS_WG_WAVES) {
+                const uint32_t a = HVS_WG_WAVES - 1u - wvs;  // which 64-uint4 piece
+                const uint32_t u = a * 64u + lane;
+                uint32_t tile = first_tile + u / HVS_I8_NRM_U4;
                 if (tile >= I1) tile = I1 - 1u;
-                const uint4* src = nrm + (size_t)tile * HVS_I8_NRM_U4 + (lane & 7u);
+                const uint4* src = nrm + (size_t)tile * HVS_I8_NRM_U4 + (u % HVS_I8_NRM_U4);
                 const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
-                    (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)&snrm[buf][0]);
-                if (lane < STG * HVS_I8_NRM_U4) {
+                    (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)&snrm[buf][a * 64u]);
+                if (u < STG * HVS_I8_NRM_U4) {
                     uint32_t keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep)
@@ -1300,11 +1318,16 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     auto load_tile = [&](uint32_t i) {
         const uint32_t rel = i - I0, buf = (rel / STG) & 1u, tt = rel % STG;
     #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = F::frag(stile[buf][tt * TILE_U4 + ks * 64 + lane]);
+        for (int ks = 0; ks < KM; ++ks) af[ks] = F::frag(stile[buf][tt * TILE_U4 + ks * 64 + lane]);
         if constexpr (kI8) {
+            // 4th k-step: lanes 0..31 hold k = 96..111 of their row (4 real dimensions from the side data, then
+            // zeros), lanes 32..63 hold k = 112..127 (zeros)
+            const uint32_t* tailw = reinterpret_cast<const uint32_t*>(&snrm[buf][tt * HVS_I8_NRM_U4]);
+            const int t4 = lane < 32u ? (int)tailw[lane & 31u] : 0;
+            af[KM] = hvs_i32x4{t4, 0, 0, 0};
     #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const hvs_i32x4 v = hvs_as_i32x4(snrm[buf][tt * HVS_I8_NRM_U4 + 2 * g4 + (lane >> 5)]);
+                const hvs_i32x4 v = hvs_as_i32x4(snrm[buf][tt * HVS_I8_NRM_U4 + 8 + 2 * g4 + (lane >> 5)]);
                 acc0[4 * g4 + 0] = v[0];
                 acc0[4 * g4 + 1] = v[1];
                 acc0[4 * g4 + 2] = v[2];
