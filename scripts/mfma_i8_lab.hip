@@ -7,6 +7,7 @@
 //   -DLAB_LDS      A fragments (4 ds_read_b128) + row norms (4 ds_read_b128) re-read from LDS every tile
 //   -DLAB_DMA      LDS-DMA of the next stage (4 tiles x 4 KiB + norms), inline asm as the kernel
 //   -DLAB_RANDOM   random int8 operands (all bits toggle)
+//   -DLAB_PAD_LDS=N  N bytes of unused LDS per workgroup (limits the workgroups per CU)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,10 @@ __global__ __launch_bounds__(256, LAB_OCC) void lab(const uint4* __restrict__ in
                                                     int ntiles, int theta_in)
 {
     __shared__ uint4 stile[2][STAGE_U4 + 256];
+#ifdef LAB_PAD_LDS
+    __shared__ uint4 spad[LAB_PAD_LDS / 16];  // occupancy limiter: -DLAB_PAD_LDS=bytes
+    if (ntiles < 0) spad[threadIdx.x] = in[threadIdx.x];
+#endif
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     union { uint4 u; i32x4 b; } c;
     i32x4 bq[LAB_QB][KS], af[KS];
@@ -105,6 +110,9 @@ __global__ __launch_bounds__(256, LAB_OCC) void lab(const uint4* __restrict__ in
         __syncthreads();
 #endif
     }
+#ifdef LAB_PAD_LDS
+    if (ntiles < 0) keep += (int)spad[threadIdx.x ^ 1].x;
+#endif
     out[blockIdx.x * 256 + threadIdx.x] = keep + (int)hits;
 }
 
