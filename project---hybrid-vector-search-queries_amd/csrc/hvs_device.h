@@ -169,6 +169,105 @@ __device__ __forceinline__ uint32_t hvs_prefix_count(uint64_t mask)
 // memory visible to the whole wave.  Returns the KEEP-th smallest key; the list then holds
 // exactly KEEP keys.  Precondition: cnt > KEEP.
 // ---------------------------------------------------------------------------------------------
+// Same contract, 8 bits per step instead of 1: a 256-bucket histogram of the undecided digit in wave-private LDS
+// (`hist`, 256 x u32), one wave-wide prefix scan to find the bucket that holds the KEEP-th key, repeat inside that
+// bucket.  Distances of one query's candidates separate within ~3 digits below their common prefix, against
+// ~25 single-bit steps of 4 ballots each: the merge kernels spend 5-6x fewer instructions here.
+template <int KEEP>
+__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t lane, uint32_t* hist)
+{
+    uint64_t k[4];
+    bool act[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t idx = lane + 64u * i;
+        act[i] = idx < cnt;
+        k[i] = act[i] ? list[idx] : ~0ull;
+    }
+    const bool valid0 = act[0], valid1 = act[1], valid2 = act[2], valid3 = act[3];
+    // common prefix of all keys (see the bit-serial version)
+    int hi;
+    uint64_t prefix;
+    {
+        const uint64_t k0 = list[0];
+        uint64_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d |= act[i] ? (k[i] ^ k0) : 0ull;
+        uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dlo |= (uint32_t)__shfl_xor((int)dlo, o);
+            dhi |= (uint32_t)__shfl_xor((int)dhi, o);
+        }
+        d = ((uint64_t)__builtin_amdgcn_readfirstlane(dhi) << 32) | __builtin_amdgcn_readfirstlane(dlo);
+        hi = d ? 63 - (int)__builtin_clzll(d) : 0;
+        prefix = hi < 63 ? (k0 & (~0ull << (hi + 1))) : 0ull;
+    }
+    uint32_t r = KEEP;  // rank of the wanted key inside the active set
+    for (;;) {          // wave-uniform
+        const int lo = hi >= 7 ? hi - 7 : 0;
+        const uint32_t dmask = (1u << (hi - lo + 1)) - 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hist[lane + 64u * i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (act[i]) atomicAdd(&hist[(uint32_t)(k[i] >> lo) & dmask], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // lane l owns buckets 4l .. 4l+3
+        const uint32_t c0 = hist[4u * lane], c1 = hist[4u * lane + 1u], c2 = hist[4u * lane + 2u], c3 = hist[4u * lane + 3u];
+        const uint32_t mine = c0 + c1 + c2 + c3;
+        uint32_t incl = mine;  // inclusive scan over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            incl += lane >= (uint32_t)o ? up : 0u;
+        }
+        const uint32_t b0 = incl - mine, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;  // keys in buckets before mine
+        // exactly one bucket has  before < r <= before + count
+        const bool h0 = b0 < r && r <= b0 + c0, h1 = b1 < r && r <= b1 + c1, h2 = b2 < r && r <= b2 + c2,
+                   h3 = b3 < r && r <= b3 + c3;
+        const uint32_t jd = h0 ? 0u : h1 ? 1u : h2 ? 2u : 3u;
+        const uint32_t jb = h0 ? b0 : h1 ? b1 : h2 ? b2 : b3;
+        const uint32_t jc = h0 ? c0 : h1 ? c1 : h2 ? c2 : c3;
+        const uint64_t hm = __ballot(h0 | h1 | h2 | h3);
+        const int src = (int)__builtin_ctzll(hm | (1ull << 63));
+        const uint32_t digit = 4u * (uint32_t)src + __builtin_amdgcn_readlane(jd, src);
+        const uint32_t before = __builtin_amdgcn_readlane(jb, src);
+        const uint32_t rem = __builtin_amdgcn_readlane(jc, src);
+        r -= before;
+        prefix |= (uint64_t)digit << lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) act[i] = act[i] && (((uint32_t)(k[i] >> lo) & dmask) == digit);
+        if (rem == 1u) {
+            // one key left under this prefix: it is the answer (keys are distinct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t mm = __ballot(act[i]);
+                if (mm != 0ull) {
+                    const int s2 = (int)__builtin_ctzll(mm);
+                    const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)k[i], s2);
+                    const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(k[i] >> 32), s2);
+                    prefix = ((uint64_t)khi << 32) | klo;
+                }
+            }
+            break;
+        }
+        if (lo == 0) break;  // every bit decided: prefix is the key
+        hi = lo - 1;
+    }
+    uint32_t base = 0;
+    const bool valid[4] = {valid0, valid1, valid2, valid3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool keep = valid[i] && k[i] <= prefix;
+        const uint64_t mask = __ballot(keep);
+        if (keep) list[base + hvs_prefix_count(mask)] = k[i];
+        base += (uint32_t)__popcll(mask);
+    }
+    return prefix;
+}
+
 template <int KEEP>
 __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t lane)
 {

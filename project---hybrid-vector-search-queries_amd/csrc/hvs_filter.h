@@ -1628,6 +1628,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                                                    const HvsQuant* __restrict__ qz)
 {
     __shared__ uint64_t sbuf[4][256];
+    __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4u + w;
@@ -1644,7 +1645,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     for (uint32_t off = 0; off < m; off += 64u) {
         if (cnt + 64u > 256u) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+            hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
             cnt = HVS_KNN;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
@@ -1654,7 +1655,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
         cnt = HVS_KNN;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
     const uint32_t* __restrict__ cand_cnt, int pad, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
 {
     __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4u + w;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
         for (uint32_t off = 0; off < m; off += 64u) {
             if (cnt + 64u > HVS_CAND_CAP) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
                 cnt = HVS_KNN;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void hvs_k_select(
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
         cnt = HVS_KNN;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __rest
                                                           uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
 {
     __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x * 4u + w;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __rest
         for (uint32_t off = 0; off < HVS_KNN; off += 64u) {
             if (cnt + 64u > HVS_CAND_CAP) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
                 cnt = HVS_KNN;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __rest
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane);
+        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
         cnt = HVS_KNN;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
