@@ -630,8 +630,15 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0, c->stream,
                        c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
                        std::max(1u, seed_chunks));
-    hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                       c->d_bounds, L.K == 0u ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+    auto launch_merge = [&](bool final) {
+        if (final)
+            hipLaunchKernelGGL(hvs_k_merge<true>, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                               c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+        else
+            hipLaunchKernelGGL(hvs_k_merge<false>, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                               c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+    };
+    launch_merge(L.K == 0u);
     // re-scoring blocks per group: each block stages the group's 128 queries in LDS first, so large batches use
     // few long-lived blocks per group (2: -4 % of the step at 262144 queries) and small batches enough blocks to
     // fill the chip
@@ -660,8 +667,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         }
         hipLaunchKernelGGL(hvs_k_rescore, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, c->d_counters);
-        hipLaunchKernelGGL(hvs_k_merge, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                           c->d_bounds, level1 == L.K ? 1 : 0, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+        launch_merge(level1 == L.K);
     }
     // queries whose candidate lists overflowed are answered again by the exact engine
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));

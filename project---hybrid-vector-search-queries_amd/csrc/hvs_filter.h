@@ -1622,8 +1622,11 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
 //   => discard iff  s~ < theta := (|q|^2 - tau (1 + 2g)) / 2 - (mu + rho + |q| E_D + e_q NB_D) - slack,
 //      slack = 1e-9 (|q|^2 + tau + band) covering the f64 evaluation of theta itself
 // ---------------------------------------------------------------------------------------------
+// (FINAL as a template parameter: the padding path's exact-order distance costs 70 VGPRs that would halve the
+// occupancy of the 13 latency-bound merges before it)
+template <bool FINAL>
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
-                                                   HvsBatch B, const HvsBounds* __restrict__ bounds, int final, int pad,
+                                                   HvsBatch B, const HvsBounds* __restrict__ bounds, int pad,
                                                    uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, int fmt,
                                                    const HvsQuant* __restrict__ qz)
 {
@@ -1638,7 +1641,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     uint64_t* buf = sbuf[w];
     uint32_t m = B.candcnt[slot];
     if (m > HVS_FCAP) m = HVS_FCAP;
-    if (m == 0u && !final) return;  // nothing new at this level: top-100, tau and theta stand
+    if (m == 0u && !FINAL) return;  // nothing new at this level: top-100, tau and theta stand
     uint32_t cnt = B.topcnt[slot];
     for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * HVS_TOPCAP + e];
     const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
@@ -1659,7 +1662,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         cnt = HVS_KNN;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-    if (!final) {
+    if constexpr (!FINAL) {
         for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * HVS_TOPCAP + e] = buf[e];
         // tau = largest kept distance once 100 are held
         float dmax = 0.0f;
