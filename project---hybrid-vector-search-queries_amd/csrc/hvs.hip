@@ -322,9 +322,9 @@ int choose_format(hvs_ctx* c)
     const double band8 = 2.0 * (double)hb.n_d8 * (double)hb.e_d8;
     const double infl16 = std::exp(std::min(50.0, z * 2.0 * band16 / sigma));
     const double infl8 = std::exp(std::min(50.0, z * 2.0 * band8 / sigma));
-    // cost model (D = 1e7 mixed batch, profiles/): BF16 filter 188 + re-scoring 38 ms per step at inflation ~1;
-    // INT8 filter ~100 ms
-    const double cost16 = 188.0 + 38.0 * infl16, cost8 = 100.0 + 38.0 * infl8;
+    // cost model in units of one INT8 filter launch (D = 1e7, 2^20 mixed queries, profiles/r01_int8): the BF16
+    // filter takes 1.53x as long, re-scoring 0.235x at inflation 1 and grows with the candidates
+    const double cost16 = 1.53 + 0.235 * infl16, cost8 = 1.0 + 0.235 * infl8;
     c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? HVS_FMT_I8 : HVS_FMT_BF16;
     if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "i8"
         if (!std::strcmp(f, "bf16")) c->planned_fmt = HVS_FMT_BF16;
