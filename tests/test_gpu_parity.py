@@ -502,3 +502,28 @@ def test_filter_engines_on_degenerate_value_ranges(fengine):
             ids, dists = e.query(q, 1.0)
             print("engine ran:", e.last_timing().engine, "fallback", e.last_timing().fallback_queries)
         T.check_parity(d, q, ids, ref, got_dists=dists)
+
+
+def test_largest_batch_2pow20_queries_filters_agree():
+    """The largest batch the library forms (2^20 queries, the bench default) at D = 10^7: the INT8 and BF16
+    filters must return identical bits for every query, and the exact scan must confirm a 2048-query sample."""
+    n, nq = 10_000_000, 1 << 20
+    with PKG.Engine(0) as e:
+        e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
+        e.gen_queries(nq, T.SEED_QUERY + 5, T.GEN_V1, 100, -1, 0)
+        res = {}
+        for engine in FILTER_ENGINES:
+            e.set_engine(engine)
+            e.query_resident(0, nq, 1.0)
+            e.sync()
+            t = e.last_timing()
+            assert t.engine == engine and t.fallback_queries == 0 and t.nq == nq
+            res[engine] = e.download_results(0, nq)
+        a, b = res[PKG.ENGINE_MFMA_I8], res[PKG.ENGINE_MFMA_FILTER]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        sel = np.arange(0, nq, nq // 2048)[:2048]
+        q = e.download_queries(0, nq)[sel]
+        e.set_engine(PKG.ENGINE_EXACT_SCAN)
+        ids, d = e.query(q, 1.0)
+        assert np.array_equal(ids, a[0][sel]) and np.array_equal(d.view(np.uint32), a[1][sel].view(np.uint32))
+        assert np.all(np.diff(a[1], axis=1) >= 0) and a[0].max() < n
