@@ -101,6 +101,9 @@ const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 1u << 20, 128u, 1u << 20);
 const uint32_t kRescoreBlocks = env_u32("HVS_RESCORE_BLOCKS", 0u, 0u, 64u);  // 0: chosen per batch
 // exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
 const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
+// INT8 tiles are built for v_mfma_i32_16x16x64_i8 (HVS_FMT_I8X16: 1.16x the pair rate of the 32x32x32 shape in the
+// filter loop, scripts/mfma_shape_lab.hip); HVS_I8_SHAPE=32 selects the 32x32x32 layout (HVS_FMT_I8) for A/B runs
+const int kI8Fmt = env_u32("HVS_I8_SHAPE", 16u, 16u, 32u) == 32u ? HVS_FMT_I8 : HVS_FMT_I8X16;
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
 
@@ -325,10 +328,10 @@ int choose_format(hvs_ctx* c)
     // cost model in units of one INT8 filter launch (D = 1e7, 2^20 mixed queries, profiles/r01_int8): the BF16
     // filter takes 1.53x as long, re-scoring 0.235x at inflation 1 and grows with the candidates
     const double cost16 = 1.53 + 0.235 * infl16, cost8 = 1.0 + 0.235 * infl8;
-    c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? HVS_FMT_I8 : HVS_FMT_BF16;
+    c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? kI8Fmt : HVS_FMT_BF16;
     if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "i8"
         if (!std::strcmp(f, "bf16")) c->planned_fmt = HVS_FMT_BF16;
-        if (!std::strcmp(f, "i8")) c->planned_fmt = HVS_FMT_I8;
+        if (!std::strcmp(f, "i8")) c->planned_fmt = kI8Fmt;
     }
     return HVS_OK;
 }
@@ -346,18 +349,24 @@ int build_tiles(hvs_ctx* c, int fmt)
     if ((rc = dev_alloc(c, &c->d_tiles_t, (size_t)0))) return rc;
     if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)0))) return rc;
     if ((rc = dev_alloc(c, &c->d_nrm_t, (size_t)0))) return rc;
-    const size_t tile_u4 = fmt == HVS_FMT_I8 ? HVS_I8_TILE_U4 : HVS_TILE_U4;
+    const size_t tile_u4 = fmt == HVS_FMT_I8 ? HVS_I8_TILE_U4 : fmt == HVS_FMT_I8X16 ? HVS_I8X16_TILE_U4 : HVS_TILE_U4;
     if ((rc = dev_alloc(c, &c->d_tiles_ct, (size_t)L.nblk * tile_u4))) return rc;
     if ((rc = dev_alloc(c, &c->d_tiles_t, (size_t)L.nblk * tile_u4))) return rc;
-    if (fmt == HVS_FMT_I8) {
-        if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)L.nblk * HVS_I8_NRM_U4))) return rc;
-        if ((rc = dev_alloc(c, &c->d_nrm_t, (size_t)L.nblk * HVS_I8_NRM_U4))) return rc;
+    if (HVS_IS_I8(fmt)) {
+        const size_t nrm_u4 = fmt == HVS_FMT_I8 ? HVS_I8_NRM_U4 : HVS_I8X16_NRM_U4;
+        if ((rc = dev_alloc(c, &c->d_nrm_ct, (size_t)L.nblk * nrm_u4))) return rc;
+        if ((rc = dev_alloc(c, &c->d_nrm_t, (size_t)L.nblk * nrm_u4))) return rc;
     }
     if (!c->d_bpos_ct && (rc = dev_alloc(c, &c->d_bpos_ct, (size_t)L.nblk))) return rc;
     if (!c->d_bpos_t && (rc = dev_alloc(c, &c->d_bpos_t, (size_t)L.nblk))) return rc;
     HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
     const dim3 grid((L.nblk + 3u) / 4u);
-    if (fmt == HVS_FMT_I8) {
+    if (fmt == HVS_FMT_I8X16) {
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8x16, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_quant,
+                           c->d_tiles_ct, reinterpret_cast<int*>(c->d_nrm_ct), c->d_bpos_ct, c->d_bounds);
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8x16, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_quant,
+                           c->d_tiles_t, reinterpret_cast<int*>(c->d_nrm_t), c->d_bpos_t, c->d_bounds);
+    } else if (fmt == HVS_FMT_I8) {
         hipLaunchKernelGGL(hvs_k_build_tiles_i8, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_quant,
                            c->d_tiles_ct, reinterpret_cast<int*>(c->d_nrm_ct), c->d_bpos_ct, c->d_bounds);
         hipLaunchKernelGGL(hvs_k_build_tiles_i8, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_quant,
@@ -375,7 +384,7 @@ int build_tiles(hvs_ctx* c, int fmt)
     HvsBounds hb{};
     HVS_HIP(c, hipMemcpy(&hb, c->d_bounds, sizeof(hb), hipMemcpyDeviceToHost));
     bool ok;
-    if (fmt == HVS_FMT_I8)
+    if (HVS_IS_I8(fmt))
         ok = std::isfinite(hb.e_d8) && std::isfinite(hb.n_d8) && hb.n_d8 < 1.0e15f;
     else
         // (norms near the f32 denormal range: BF16 operands might be flushed by the matrix pipe, which the
@@ -452,12 +461,12 @@ int build_index(hvs_ctx* c)
     }
     int fmt = c->planned_fmt;
     if (c->engine == HVS_ENGINE_MFMA_FILTER) fmt = HVS_FMT_BF16;
-    if (c->engine == HVS_ENGINE_MFMA_I8 && c->i8_usable) fmt = HVS_FMT_I8;
+    if (c->engine == HVS_ENGINE_MFMA_I8 && c->i8_usable) fmt = kI8Fmt;
     if ((rc = build_tiles(c, fmt))) {
         free_index(c);
         return rc;
     }
-    if (!c->have_index && fmt == HVS_FMT_I8 && (rc = build_tiles(c, HVS_FMT_BF16))) {
+    if (!c->have_index && HVS_IS_I8(fmt) && (rc = build_tiles(c, HVS_FMT_BF16))) {
         free_index(c);
         return rc;
     }
@@ -654,7 +663,10 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
             const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
             if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
             const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
-            if (fmt == HVS_FMT_I8)
+            if (fmt == HVS_FMT_I8X16)
+                hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,
+                                   c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
+            else if (fmt == HVS_FMT_I8)
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_I8>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
                                    c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
             else
@@ -665,8 +677,12 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
                 c->n_launch_events++;
             }
         }
-        hipLaunchKernelGGL(hvs_k_rescore, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct,
-                           c->d_perm_t, c->d_counters);
+        if (fmt == HVS_FMT_I8X16)
+            hipLaunchKernelGGL(hvs_k_rescore<true>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
+                               sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_counters);
+        else
+            hipLaunchKernelGGL(hvs_k_rescore<false>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
+                               sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_counters);
         launch_merge(level1 == L.K);
     }
     // queries whose candidate lists overflowed are answered again by the exact engine
@@ -702,7 +718,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     if (mfma) {
         // the tiles exist in one format at a time: an engine choice made after the load rebuilds them
         int want = c->engine == HVS_ENGINE_MFMA_FILTER ? HVS_FMT_BF16
-                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable ? HVS_FMT_I8 : HVS_FMT_BF16)
+                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable ? kI8Fmt : HVS_FMT_BF16)
                                                        : c->planned_fmt;
         if (want != c->tile_fmt) {
             const int had = c->tile_fmt;
@@ -728,7 +744,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     c->timing = hvs_timing{};
     c->timing.nq = nq;
-    c->timing.engine = mfma ? (c->tile_fmt == HVS_FMT_I8 ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
+    c->timing.engine = mfma ? (HVS_IS_I8(c->tile_fmt) ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
     c->timing.fallback_queries = c->fallback_queries;
     c->timing_valid = true;

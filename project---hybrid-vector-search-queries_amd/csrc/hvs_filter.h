@@ -77,12 +77,21 @@ typedef int hvs_i32x16 __attribute__((ext_vector_type(16)));
 #define HVS_FMT_NONE 0
 #define HVS_FMT_BF16 1
 #define HVS_FMT_I8 2
+#define HVS_FMT_I8X16 3        // INT8 operands laid out for v_mfma_i32_16x16x64_i8 (same quantisation and bound as HVS_FMT_I8)
+#define HVS_IS_I8(fmt) ((fmt) == HVS_FMT_I8 || (fmt) == HVS_FMT_I8X16)
 #define HVS_I8_KSTEPS 4        // 4 MFMA k-steps of 32 (K padded 100 -> 128)
 #define HVS_I8_KMEM 3          // k-steps stored as full fragments (dims 0..95); the 4th holds 4 real dimensions
 #define HVS_I8_TILE_U4 (HVS_I8_KMEM * 64)  // uint4 per 32-row INT8 tile (3 KiB)
 #define HVS_I8_NRM_U4 16       // uint4 of side data per tile: [0,8) dims 96..99 of the 32 rows (4 x int8 each),
                                // [8,16) the rows' accumulator inits (32 x int32)
 #define HVS_I8_PAD_NORM (-(1 << 30))  // accumulator init of a padding row: can never reach a threshold
+// HVS_FMT_I8X16: a 32-row tile = 4 fragments of 64 lanes x 16 B (row block rb = 0,1 x k-step ks = 0,1; fragment
+// f = 2 rb + ks; lane l: row 16 rb + (l & 15), k = 64 ks + 16 (l >> 4) + 0..15; K padded 100 -> 128 with zeros)
+// = 4 KiB, plus the 32 accumulator inits (8 uint4) as side data
+#define HVS_I8X16_FRAGS 4
+#define HVS_I8X16_TILE_U4 (HVS_I8X16_FRAGS * 64)
+#define HVS_I8X16_NRM_U4 8
+#define HVS_I8X16_QSUB 16      // queries per B-operand fragment (8 sub-blocks per 128-query group)
 
 // ---------------------------------------------------------------------------------------------
 // order-preserving integer keys of f32 attributes.  -0 is folded into +0 (they compare equal in
@@ -394,6 +403,64 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles_i8(const float* __restr
     }
 }
 
+// HVS_FMT_I8X16: one wave per storage block.  Same quantisation, accumulator inits and bounds as
+// hvs_k_build_tiles_i8; only the operand layout differs (v_mfma_i32_16x16x64_i8: lane l of fragment (rb, ks) holds
+// row 16 rb + (l & 15), k = 64 ks + 16 (l >> 4) + 0..15).
+__global__ __launch_bounds__(256) void hvs_k_build_tiles_i8x16(const float* __restrict__ D, uint32_t n,
+                                                               const uint32_t* __restrict__ perm, HvsLevels L,
+                                                               const HvsQuant* __restrict__ qz, uint4* __restrict__ tiles,
+                                                               int* __restrict__ norms, uint32_t* __restrict__ blockpos,
+                                                               HvsBounds* __restrict__ bounds)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= L.nblk) return;
+    const uint32_t b = hvs_storage_to_block(L, idx);
+    if (lane == 0u) blockpos[idx] = b;
+    const double sd = qz->sd, inv_sd = qz->inv_sd;
+    if (lane < 32u) {  // lane = row: norm term and row bounds
+        const uint32_t pos = b * 32u + lane;
+        const bool valid = pos < n;
+        const float* __restrict__ row = D + (size_t)(valid ? perm[pos] : 0u) * HVS_DCOLS + 2;
+        double nd = 0.0, e2 = 0.0;
+        for (int k = 0; k < HVS_NDIM; ++k) {
+            const double x = (double)row[k] - (double)qz->center[k];
+            const double xq = sd * (double)hvs_quant_i8(x, inv_sd);
+            nd += x * x;
+            e2 += (x - xq) * (x - xq);
+        }
+        int nh = HVS_I8_PAD_NORM;
+        if (valid) {
+            const double v = floor(-0.5 * nd * inv_sd * inv_sd);
+            nh = v > -1.0e9 ? (int)v : HVS_I8_PAD_NORM;
+            hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30));
+            hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd) * (1.0 + 1e-9) + 1e-30));
+        }
+        norms[(size_t)idx * 32u + lane] = nh;
+    }
+#pragma unroll
+    for (int f = 0; f < HVS_I8X16_FRAGS; ++f) {
+        const int rbk = f >> 1, ks = f & 1;
+        const uint32_t pos = b * 32u + 16u * (uint32_t)rbk + (lane & 15u);
+        const bool valid = pos < n;
+        const float* __restrict__ row = D + (size_t)(valid ? perm[pos] : 0u) * HVS_DCOLS + 2;
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 64 * ks + 16 * (int)(lane >> 4) + 4 * p + e;
+                int v = 0;
+                if (valid && k < HVS_NDIM) v = hvs_quant_i8((double)row[k] - (double)qz->center[k], inv_sd);
+                word |= ((uint32_t)v & 0xFFu) << (8 * e);
+            }
+            w[p] = word;
+        }
+        tiles[((size_t)idx * HVS_I8X16_FRAGS + f) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Planner inputs in one pass over a sample of rows (stride `step`): the bounds BOTH formats would get
 // (from the sampled rows only -- estimates, the formats' own build kernels compute the real maxima) and
 // the spread of squared distances between sampled row pairs.  One lane per sampled row.
@@ -560,6 +627,23 @@ __device__ __forceinline__ uint32_t hvs_entry_pos(uint64_t e, uint32_t r)
     return bp * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
+// HVS_FMT_I8X16 entries: the lane of a 16x16 accumulator block holds ONE query and 4 consecutive rows, two row blocks per
+// tile: bits 0..7 accumulator mask (bit b = 4 rb + i: row 16 rb + 4 quad + i of the block), 8..9 quad (lane >> 4),
+// 16..37 block position, 39..63 slot.
+__device__ __forceinline__ uint64_t hvs_entry16_make(uint32_t slot, uint32_t bp, uint32_t quad, uint32_t mask8)
+{
+    const uint32_t lo = (bp << 16) | (quad << 8) | mask8;
+    const uint32_t hi = (slot << 7) | (bp >> 16);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t hvs_entry16_mask(uint64_t e) { return (uint32_t)e & 0xFFu; }
+__device__ __forceinline__ uint32_t hvs_entry16_pos(uint64_t e, uint32_t b)
+{
+    const uint32_t bp = (uint32_t)(e >> 16) & (HVS_ENTRY_MAX_BLOCKS - 1u);
+    const uint32_t quad = (uint32_t)(e >> 8) & 3u;
+    return bp * 32u + 16u * (b >> 2) + 4u * quad + (b & 3u);
+}
+
 // class rank of a query type: (C,T)-ordering classes first, the T-ordering class (type 2) last
 __device__ __forceinline__ uint32_t hvs_type_rank(uint32_t type)
 {
@@ -694,7 +778,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
         const HvsQParams p = hvs_parse_query(q);
         hvs_query_range(p, keys_ct, keys_t, n, a, b);
-        if (fmt == HVS_FMT_I8) {
+        if (HVS_IS_I8(fmt)) {
             // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2
             const double sd = qz->sd, inv_sd = qz->inv_sd;
             for (int k = 0; k < HVS_NDIM; ++k) {
@@ -732,7 +816,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     B.overflow[s] = (qi != 0xFFFFFFFFu && (clipped || !(qn < 1.0e30))) ? 1u : 0u;
     B.tau[s] = __builtin_inff();
     // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
-    if (fmt == HVS_FMT_I8)
+    if (HVS_IS_I8(fmt))
         B.thetai[s] = b > a ? (int)0x80000000 : 0x7FFFFFFF;
     else
         B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
@@ -764,6 +848,33 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
         B.gord[g] = B.rank[g * HVS_GROUP] == 4u ? 1u : 0u;
         B.paircnt[g] = 0;
         B.goverflow[g] = 0;
+    }
+    if (fmt == HVS_FMT_I8X16) {
+        // B fragments of v_mfma_i32_16x16x64_i8: fragment (sub-block j of 16 queries, k-step ks): lane l holds query
+        // column 16 j + (l & 15), k = 64 ks + 16 (l >> 4) + 0..15; stored [group][j][ks][lane]
+        const double inv_sd = qz->inv_sd;
+        constexpr uint32_t kSub = HVS_GROUP / HVS_I8X16_QSUB;
+        for (uint32_t e = t; e < kSub * 2u * 64u; e += HVS_GROUP) {
+            const uint32_t j = e / 128u, ks = (e / 64u) & 1u, l = e & 63u;
+            const uint32_t slot = g * HVS_GROUP + j * HVS_I8X16_QSUB + (l & 15u);
+            const uint32_t qi = B.qid[slot];
+            uint32_t w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int k = 64 * (int)ks + 16 * (int)(l >> 4) + 4 * p + e2;
+                    int v = 0;
+                    if (qi != 0xFFFFFFFFu && k < HVS_NDIM)
+                        v = hvs_quant_i8((double)Q[(size_t)qi * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
+                    word |= ((uint32_t)v & 0xFFu) << (8 * e2);
+                }
+                w[p] = word;
+            }
+            B.bfrag[((size_t)(g * kSub + j) * 2u + ks) * 64u + l] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
     }
     if (fmt == HVS_FMT_I8) {
         // INT8 B fragments: lane l of k-step ks holds query column (l & 31), k = 32 ks + 16 (l >> 5) + 0..15
@@ -1453,6 +1564,287 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 }
 
 // ---------------------------------------------------------------------------------------------
+// hvs_k_filter_i8x16 -- the INT8 filter on v_mfma_i32_16x16x64_i8 (tile format HVS_FMT_I8X16).
+//
+// Same work decomposition, LDS-DMA staging, survivor buffers and bound as hvs_k_filter_mfma<HVS_FMT_I8>; the matrix
+// shape differs.  In the filter-shaped loop (A fragments + accumulator inits re-read from LDS per tile, max/threshold
+// epilogue, two waves per SIMD, random operands) the 16x16x64 shape sustains 1.16-1.17x the pair rate of 32x32x32 on
+// this chip (scripts/mfma_shape_lab.hip: 12.8 vs 10.9 G 32x32 pair blocks/s) -- the chip holds a higher clock under
+// the 16x16 instruction stream (MI355X_MICROARCH.md, DVFS give-back (7), reports the same for BF16).
+//
+// Per tile and wave: 4 ds_read_b128 fetch the A fragments (row block rb = 0,1 x k-step ks = 0,1), 2 ds_read_b128 the
+// accumulator inits (a lane's 4 accumulators are 4 consecutive rows); against the wave's 8 resident sub-blocks of 16
+// queries (B fragments in 64 VGPRs) 32 v_mfma_i32_16x16x64_i8 (2 row blocks x 8 sub-blocks x 2 k-steps) yield
+// S[row][query] = qq.dq + nh exactly.  A lane's 8 accumulators per sub-block belong to ONE query: max chain, one
+// compare against the lane's threshold, scalar hit masks; survivors leave as 8-byte entries (hvs_entry16_*).
+// ---------------------------------------------------------------------------------------------
+#define HVS_HITMASK8_ASM                                                                                                 \
+    "v_mov_b32 %0, 0\n\tv_cmp_ge_i32_e64 %1, %12, %13\n\tv_cmp_ge_i32_e64 %2, %11, %13\n\tv_cmp_ge_i32_e64 %3, %10, %13\n\t" \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_ge_i32_e64 %1, %9, %13\n\t"                                            \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_ge_i32_e64 %2, %8, %13\n\t"                                            \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_ge_i32_e64 %3, %7, %13\n\t"                                            \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_ge_i32_e64 %1, %6, %13\n\t"                                            \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_ge_i32_e64 %2, %5, %13\n\t"                                            \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"                                                                           \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"                                                                           \
+    "s_nop 1\n\t"                                                                                                        \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %2"
+// bit b = 4 rb + i of the result = (acc[rb][i] >= th)
+__device__ __forceinline__ uint32_t hvs_hit_mask8(const hvs_i32x4& a0, const hvs_i32x4& a1, int th)
+{
+    uint32_t m;
+    uint64_t s0, s1, s2, sc;
+    asm volatile(HVS_HITMASK8_ASM
+                 : "=&v"(m), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(sc)
+                 : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(th));
+    return m;
+}
+
+__global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_i8x16(
+    const uint4* __restrict__ tiles_ct, const uint4* __restrict__ tiles_t, const uint4* __restrict__ nrm_ct,
+    const uint4* __restrict__ nrm_t, const uint32_t* __restrict__ bpos_ct, const uint32_t* __restrict__ bpos_t, HvsLevels L,
+    uint32_t level, HvsBatch B, unsigned long long* __restrict__ counters)
+{
+    constexpr int STG = HVS_STAGE_I8;
+    constexpr int TILE_U4 = HVS_I8X16_TILE_U4;
+    constexpr int NRM_U4 = HVS_I8X16_NRM_U4;
+    constexpr int NSUB = HVS_GROUP / HVS_I8X16_QSUB;  // 8 sub-blocks of 16 queries per wave
+    static_assert(STG * NRM_U4 == 64, "the side data of a stage is one LDS-DMA wave-instruction");
+    static_assert((STG * HVS_I8X16_FRAGS) % HVS_WG_WAVES == 0, "chunks of a stage divide over the waves");
+    __shared__ uint4 stile[2][STG * TILE_U4];  // 2 x 32 KiB
+    __shared__ uint4 snrm[2][STG * NRM_U4];    // 2 x 1 KiB
+    __shared__ uint64_t sbuf[HVS_WG_WAVES][256];
+    __shared__ uint32_t srange[HVS_WG_WAVES][2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * HVS_WG_WAVES + wv;
+    const uint32_t gq = blockIdx.x * HVS_WG_WAVES;
+    const uint32_t ord = B.gord[gq];
+    const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
+    const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
+    const uint4* __restrict__ nrm = ord ? nrm_t : nrm_ct;
+    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
+    uint32_t i0 = 0, i1 = 0;
+    if (g < B.ngroups && B.gord[g] == ord) {
+        uint32_t lo, hi;
+        hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
+        if (seg_lo < hi && seg_lo + HVS_SEG > lo) {
+            i0 = seg_lo > lo ? seg_lo : lo;
+            i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+        }
+    }
+    if (lane == 0u) {
+        srange[wv][0] = i0 < i1 ? i0 : 0xFFFFFFFFu;
+        srange[wv][1] = i0 < i1 ? i1 : 0u;
+    }
+    __syncthreads();
+    uint32_t I0 = srange[0][0], I1 = srange[0][1];
+#pragma unroll
+    for (int w = 1; w < HVS_WG_WAVES; ++w) {
+        I0 = srange[w][0] < I0 ? srange[w][0] : I0;
+        I1 = srange[w][1] > I1 ? srange[w][1] : I1;
+    }
+    if (I0 >= I1) return;  // uniform over the workgroup
+    I0 = __builtin_amdgcn_readfirstlane(I0);
+    I1 = __builtin_amdgcn_readfirstlane(I1);
+    i0 = __builtin_amdgcn_readfirstlane(i0);
+    i1 = __builtin_amdgcn_readfirstlane(i1);
+    const bool active = i0 < i1;
+    const uint32_t gg = active ? g : gq;
+
+    // resident query operands: sub-block j, lane l <-> query slot 16 j + (l & 15)
+    hvs_i32x4 bq[NSUB][2];
+    int theta[NSUB];
+    uint32_t ra[NSUB], rb[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        const uint32_t slot = gg * HVS_GROUP + j * HVS_I8X16_QSUB + (lane & 15u);
+        theta[j] = B.thetai[slot];
+        ra[j] = B.ra[slot];
+        rb[j] = B.rb[slot];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bq[j][ks] = hvs_as_i32x4(B.bfrag[((size_t)(gg * NSUB + j) * 2u + ks) * 64u + lane]);
+    }
+    uint64_t* __restrict__ lbuf = sbuf[wv];
+    uint32_t wcnt = 0;
+    uint32_t nblocks = 0;
+
+    auto flush = [&]() {
+        if (wcnt == 0u) return;
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(&B.paircnt[g], wcnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (base + wcnt <= HVS_GCAP) {
+            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * HVS_GCAP + base + e] = lbuf[e];
+        } else if (lane == 0u) {
+            B.goverflow[g] = 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        wcnt = 0;
+    };
+
+    // LDS-DMA: a stage = 8 tiles x 4 fragments = 32 chunks of 1 KiB (8 per wave) + 1 chunk of accumulator inits
+    constexpr int kChunksPerWave = STG * HVS_I8X16_FRAGS / HVS_WG_WAVES;
+    auto dma = [&](const uint4* src, const uint4* dst) {
+        const uint32_t lds_addr =
+            __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)dst);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_addr)
+                     : "memory");
+    };
+    auto issue_stage = [&](uint32_t buf, uint32_t first_tile) {
+        const uint32_t wvs = __builtin_amdgcn_readfirstlane(wv);
+#pragma unroll
+        for (int k = 0; k < kChunksPerWave; ++k) {
+            const uint32_t c = wvs + (uint32_t)HVS_WG_WAVES * (uint32_t)k;
+            uint32_t tile = first_tile + c / HVS_I8X16_FRAGS;
+            if (tile >= I1) tile = I1 - 1u;  // tail of the last stage: re-read a valid tile, never used
+            dma(tiles + (size_t)tile * TILE_U4 + (c % HVS_I8X16_FRAGS) * 64u + lane, &stile[buf][c * 64u]);
+        }
+        if (wvs == HVS_WG_WAVES - 1u) {
+            uint32_t tile = first_tile + lane / NRM_U4;
+            if (tile >= I1) tile = I1 - 1u;
+            dma(nrm + (size_t)tile * NRM_U4 + (lane % NRM_U4), &snrm[buf][0]);
+        }
+    };
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    hvs_i32x4 af[HVS_I8X16_FRAGS];
+    hvs_i32x4 nh[2];
+    hvs_i32x4 acc[2][NSUB];
+    uint64_t hm[NSUB];
+    uint32_t bp = 0;
+    auto load_tile = [&](uint32_t i) {
+        const uint32_t rel = i - I0, buf = (rel / STG) & 1u, tt = rel % STG;
+#pragma unroll
+        for (int f = 0; f < HVS_I8X16_FRAGS; ++f) af[f] = hvs_as_i32x4(stile[buf][tt * TILE_U4 + f * 64 + lane]);
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) nh[r2] = hvs_as_i32x4(snrm[buf][tt * NRM_U4 + 4 * r2 + (lane >> 4)]);
+        bp = __builtin_amdgcn_readfirstlane(bpos[i]);
+    };
+    // The 32 matrix instructions of a tile in two groups of 16 (k-step 0 of every accumulator block, then k-step 1,
+    // accumulating IN PLACE): each instruction of the second group depends on one issued 16 instructions (>= 256
+    // cycles) earlier, so none waits.  Written as inline asm on purpose: left to the compiler, each block's two k-steps
+    // are paired back to back with the block's max chain right behind them (2-7 wait states per instruction, ~40 s_nop
+    // per tile), or -- with scheduling barriers -- the second group is not accumulated in place, which costs 64 more
+    // registers and 12 v_mov_b64 per tile to shuffle the next tile's fragments.  The compiler does not see matrix
+    // instructions inside asm, so the wait states it would insert are guaranteed by construction instead:
+    //   * operands come from LDS / global loads (s_waitcnt is operand-based and still inserted), never from a VALU
+    //     instruction right in front of the block;
+    //   * a k-step-1 instruction reads an accumulator written 16 matrix instructions earlier;
+    //   * the epilogue reads the accumulators in issue order (block j = 0 first); the youngest one (j = 7) is read
+    //     after >= 6 LDS reads and >= 28 vector instructions, far beyond the 4-pass result latency;
+    //   * the fragment / init registers are overwritten only by LDS reads issued after the last matrix instruction.
+    auto chains = [&]() {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(acc[r2][j]) : "v"(af[2 * r2]), "v"(bq[j][0]), "v"(nh[r2]));
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[r2][j]) : "v"(af[2 * r2 + 1]), "v"(bq[j][1]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto imax = [](int a, int b) { return a > b ? a : b; };
+    // ONE copy of the tile body: blocks inside every lane's own range (`inner`, wave-uniform, the common case) skip
+    // the 16 per-lane range compares through a small branch instead of a second copy of the whole body (with two
+    // copies the register allocator shuffled the 24 fragment registers at every loop back-edge)
+    auto epilogue = [&](uint32_t bpx, bool inner) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            int m = imax(imax(acc[0][j][0], acc[0][j][1]), acc[0][j][2]);  // v_max3 chain
+            m = imax(imax(m, acc[0][j][3]), acc[1][j][0]);
+            m = imax(imax(m, acc[1][j][1]), acc[1][j][2]);
+            m = imax(m, acc[1][j][3]);
+            hm[j] = __ballot(m >= theta[j]);
+            if (j == NSUB / 2 - 1) __builtin_amdgcn_sched_barrier(0);  // (the younger accumulators are read last)
+        }
+        if (!inner) {
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) hm[j] &= __ballot(bpx * 32u + 32u > ra[j]) & __ballot(bpx * 32u < rb[j]);
+        }
+    };
+    auto survivors = [&](int j, uint32_t bpx, bool inner) {
+        uint32_t mask = hvs_hit_mask8(acc[0][j], acc[1][j], theta[j]);
+        if (!inner) mask = ((bpx * 32u + 32u > ra[j]) & (bpx * 32u < rb[j])) ? mask : 0u;
+        const uint32_t slot = g * HVS_GROUP + j * HVS_I8X16_QSUB + (lane & 15u);
+        const uint64_t nz = __ballot(mask != 0u);
+        if (mask != 0u) lbuf[wcnt + hvs_prefix_count(nz)] = hvs_entry16_make(slot, bpx, lane >> 4, mask);
+        wcnt += (uint32_t)__popcll(nz);
+        if (wcnt > 192u) flush();
+    };
+    uint32_t ra_max = 0u, rb_min = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        const bool live = rb[j] > ra[j];
+        ra_max = max(ra_max, live ? ra[j] : 0u);
+        rb_min = min(rb_min, live ? rb[j] : 0xFFFFFFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ra_max = max(ra_max, (uint32_t)__shfl_xor((int)ra_max, o));
+        rb_min = min(rb_min, (uint32_t)__shfl_xor((int)rb_min, o));
+    }
+    ra_max = __builtin_amdgcn_readfirstlane(ra_max);
+    rb_min = __builtin_amdgcn_readfirstlane(rb_min);
+
+    const uint32_t nstage = hvs_ceil_div(I1 - I0, STG);
+    issue_stage(0u, I0);
+    stage_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): clears the compiler's scoreboard (see hvs_k_filter_mfma)
+    // Tile t: [32 matrix instructions] [LDS reads of tile t+1's fragments, when it sits in the same stage] [epilogue of
+    // tile t] [survivors, rarely].  The fragment registers are dead once the last matrix instruction has issued, so the
+    // next tile's reads travel under the epilogue's ~50 vector instructions instead of in front of the next matrix block.
+    auto tile_body = [&](uint32_t bpx, bool inner, uint32_t inext) {
+        chains();
+        load_tile(inext);  // (always: a conditional load would make the compiler copy the 24 fragment registers per tile)
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(bpx, inner);
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) any |= hm[j];
+        if (any != 0ull) {
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j)
+                if (hm[j] != 0ull) survivors(j, bpx, inner);
+        }
+    };
+    for (uint32_t st = 0; st < nstage; ++st) {
+        if (st + 1u < nstage) issue_stage((st & 1u) ^ 1u, I0 + (st + 1u) * STG);
+        // this wave's tiles of the stage: [t0, t1)
+        const uint32_t s0 = I0 + st * STG;
+        const uint32_t t0 = i0 > s0 ? i0 : s0;
+        const uint32_t t1 = i1 < s0 + STG ? i1 : s0 + STG;  // (i1 <= I1)
+        if (active && t0 < t1) {
+            load_tile(t0);
+#pragma unroll 1
+            for (uint32_t i = t0; i < t1; ++i) {
+                ++nblocks;
+                wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+                const uint32_t bpx = bp;
+                const bool inner = bpx * 32u >= ra_max && bpx * 32u + 32u <= rb_min;
+                const uint32_t inext = i + 1u < t1 ? i + 1u : i;  // (last tile of the stage: re-read this one, unused)
+                tile_body(bpx, inner, inext);
+            }
+        }
+        stage_barrier();
+    }
+    if (active) {
+        flush();
+        if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // hvs_k_rescore -- exact-order distances of the filter's survivors, key appended to the slot's list.
 //
 // Front end (per wave, 64 survivor entries at a time, lane = entry): the k-th set bit of every entry's mask is
@@ -1467,6 +1859,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
 // re-fetched lines from L2/HBM many times.)
 // ---------------------------------------------------------------------------------------------
+// E16: entries of the 16x16 tile format (hvs_entry16_*) instead of the 32x32 formats' (hvs_entry_*)
+template <bool E16>
 __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const float* __restrict__ D, uint32_t n, uint32_t sn, const float* __restrict__ Q,
                                                      HvsBatch B, const uint32_t* __restrict__ perm_ct,
                                                      const uint32_t* __restrict__ perm_t,
@@ -1497,6 +1891,8 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     const uint32_t j = lane & 7u;
     uint64_t* list = slist[w];
     uint32_t npairs = 0;  // wave-uniform
+    auto emask = [](uint64_t e) -> uint32_t { return E16 ? hvs_entry16_mask(e) : hvs_entry_mask(e); };
+    auto epos = [](uint64_t e, uint32_t r) -> uint32_t { return E16 ? hvs_entry16_pos(e, r) : hvs_entry_pos(e, r); };
 
     // exact distances of list[0..cnt) = (slot << 32 | row id).  HVS_RESCORE_UNROLL groups of 8 pairs per pass: their
     // row loads are all issued before the first use, so a wave keeps 32 rows in flight
@@ -1577,8 +1973,8 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
         Staged t;
         t.ent = ent;
         t.ra = t.rb = t.id0 = 0u;
-        const uint32_t m = hvs_entry_mask(ent);
-        t.pos0 = hvs_entry_pos(ent, (uint32_t)__builtin_ctz(m | 0x10000u) & 15u);
+        const uint32_t m = emask(ent);
+        t.pos0 = epos(ent, (uint32_t)__builtin_ctz(m | 0x10000u) & 15u);
         if (m != 0u) {
             const uint32_t es = hvs_entry_slot(ent);
             t.ra = B.ra[es];
@@ -1593,13 +1989,13 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
         const Staged nxt = stage(ent_next);                    // loads in flight while `cur` is scored
         ent_next = load_entry(base + 2u * stride);
         const uint32_t eslot = hvs_entry_slot(cur.ent);
-        uint32_t mask = hvs_entry_mask(cur.ent);
+        uint32_t mask = emask(cur.ent);
         round((mask != 0u) & (cur.pos0 >= cur.ra) & (cur.pos0 < cur.rb), eslot, cur.id0);
         mask &= mask - 1u;
         while (__ballot(mask != 0u) != 0ull) {  // entries with more than one bit (few)
             const uint32_t r = (uint32_t)__builtin_ctz(mask | 0x10000u);
             mask &= mask - 1u;
-            const uint32_t pos = hvs_entry_pos(cur.ent, r & 15u);
+            const uint32_t pos = epos(cur.ent, r & 15u);
             const bool c = (r < 16u) & (pos >= cur.ra) & (pos < cur.rb);
             round(c, eslot, c ? perm[pos] : 0u);
         }
@@ -1674,8 +2070,8 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
             B.candcnt[slot] = 0;
             float tau = __builtin_inff();
             float theta = B.rb[slot] > B.ra[slot] ? -__builtin_inff() : __builtin_inff();
-            if (fmt == HVS_FMT_I8) {
-                // INT8 format (see "INT8 filter" above): S = qq.dq + nh is exact, the band has no accumulation term
+            if (HVS_IS_I8(fmt)) {
+                // INT8 formats (see "INT8 filter" above): S = qq.dq + nh is exact, the band has no accumulation term
                 int ti = B.rb[slot] > B.ra[slot] ? (int)0x80000000 : 0x7FFFFFFF;
                 if (cnt >= HVS_KNN) {
                     tau = dmax;

@@ -1,0 +1,211 @@
+// Lab (round 2): which INT8 MFMA shape should the filter loop be built on?
+//   part 1 -- bare chains, operands in registers, constant operands (clock stays up): time per instruction of
+//             v_mfma_i32_32x32x32_i8, v_mfma_i32_16x16x64_i8 and the legacy half-K forms 32x32x16 / 16x16x32
+//             (is a K=16 tail step cheaper than a zero-padded K=32 one?)
+//   part 2 -- the filter loop's shape on RANDOM operands (DVFS regime): A fragments + accumulator inits re-read
+//             from LDS for every tile, max/threshold epilogue, one barrier per 8 tiles; 32x32x32 with 4 query
+//             blocks of 32 per wave against 16x16x64 with 8 query blocks of 16 (same 32 rows x 128 queries per
+//             wave and tile, same 64 B-operand and 64 accumulator registers).  MI355X_MICROARCH.md "DVFS
+//             give-back (7)" reports 1.12-1.15x for the 16x16 BF16 shape in this regime.
+// build: hipcc --offload-arch=gfx950 -O3 scripts/mfma_shape_lab.hip -o shape_lab.out
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// ---- part 1 ---------------------------------------------------------------------------------------------
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void bare(const uint4* __restrict__ in, int* __restrict__ out, int iters)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    union { uint4 u; i32x4 v; long l[2]; } a, b;
+    a.u = in[lane];
+    b.u = in[64 + lane];
+    int keep = 0;
+    if constexpr (SHAPE == 0) {  // 32x32x32
+        i32x16 c[4] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a.v, b.v, c[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) keep += c[j][0];
+    } else if constexpr (SHAPE == 1) {  // 16x16x64
+        i32x4 c[4] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a.v, b.v, c[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) keep += c[j][0];
+    } else if constexpr (SHAPE == 2) {  // legacy 32x32x16
+        i32x16 c[4] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a.l[0], b.l[0], c[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) keep += c[j][0];
+    } else {  // legacy 16x16x32
+        i32x4 c[4] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a.l[0], b.l[0], c[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) keep += c[j][0];
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = keep;
+}
+
+// ---- part 2 ---------------------------------------------------------------------------------------------
+#define TILE_U4 (4 * 64 + 8)  // 4 KiB of A fragments + 32 int32 accumulator inits
+#define STG 8
+template <int SHAPE16, int OCC>
+__global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, int* __restrict__ out, int ntiles, int theta_in)
+{
+    __shared__ uint4 stile[2][STG * TILE_U4];
+    __shared__ uint4 spad[OCC == 1 ? 2048 : 1];  // 32 KiB more: one workgroup per CU = one wave per SIMD
+    if (ntiles < 0) spad[threadIdx.x % (OCC == 1 ? 2048 : 1)] = in[threadIdx.x];
+    const unsigned lane = threadIdx.x & 63u;
+    union { uint4 u; i32x4 v; } c;
+    i32x4 bq[16];  // 64 B-operand registers either way
+    for (int q = 0; q < 16; ++q) {
+        c.u = in[(q % 20) * 64 + lane];
+        bq[q] = c.v;
+        asm volatile("" : "+v"(bq[q]));
+    }
+    for (int e = threadIdx.x; e < 2 * STG * TILE_U4; e += 256) (&stile[0][0])[e] = in[(e * 7) % (20 * 64)];
+    __syncthreads();
+    int theta[8];
+    for (int q = 0; q < 8; ++q) theta[q] = theta_in + q;
+    int keep = 0;
+    unsigned hits = 0;
+    const int nstage = ntiles / STG;
+    for (int st = 0; st < nstage; ++st) {
+        const unsigned cur = st & 1;
+#pragma unroll 1
+        for (int tt = 0; tt < STG; ++tt) {
+            i32x4 af[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c.u = stile[cur][tt * TILE_U4 + s * 64 + lane];
+                af[s] = c.v;
+            }
+            if constexpr (SHAPE16) {
+                // rows of a lane's 4 accumulators: 16 rb + 4 (lane >> 4) + 0..3 -> one b128 read per row block
+                i32x4 nrm[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    c.u = stile[cur][tt * TILE_U4 + 256 + 4 * rb + (lane >> 4)];
+                    nrm[rb] = c.v;
+                }
+                // af[0], af[1]: row block 0, k-steps 0, 1;  af[2], af[3]: row block 1
+                i32x4 acc[2][8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) acc[rb][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * rb], bq[2 * q], nrm[rb], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        acc[rb][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * rb + 1], bq[2 * q + 1], acc[rb][q], 0, 0, 0);
+                bool anyhit = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int m = max(max(acc[0][q][0], acc[0][q][1]), acc[0][q][2]);
+                    m = max(max(m, acc[0][q][3]), acc[1][q][0]);
+                    m = max(max(m, acc[1][q][1]), acc[1][q][2]);
+                    m = max(m, acc[1][q][3]);
+                    anyhit = anyhit | (m >= theta[q]);
+                }
+                if (__ballot(anyhit) != 0ull) {
+                    hits++;
+                    keep += acc[0][0][3];
+                }
+            } else {
+                i32x16 nrm;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    c.u = stile[cur][tt * TILE_U4 + 256 + 2 * g4 + (lane >> 5)];
+                    nrm[4 * g4 + 0] = c.v[0];
+                    nrm[4 * g4 + 1] = c.v[1];
+                    nrm[4 * g4 + 2] = c.v[2];
+                    nrm[4 * g4 + 3] = c.v[3];
+                }
+                i32x16 acc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bq[4 * q], nrm, 0, 0, 0);
+#pragma unroll
+                    for (int s = 1; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], bq[4 * q + s], acc[q], 0, 0, 0);
+                }
+                bool anyhit = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int m = max(max(acc[q][0], acc[q][1]), acc[q][2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) m = max(max(m, acc[q][r]), acc[q][r + 1]);
+                    m = max(m, acc[q][15]);
+                    anyhit = anyhit | (m >= theta[q]);
+                }
+                if (__ballot(anyhit) != 0ull) {
+                    hits++;
+                    keep += acc[0][3];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (ntiles < 0) keep += (int)spad[(threadIdx.x ^ 1) % (OCC == 1 ? 2048 : 1)].x;
+    out[blockIdx.x * 256 + threadIdx.x] = keep + (int)hits;
+}
+
+static float run(void (*launch)(int), int reps)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(a);
+        launch(r);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms < best ? ms : best;
+    }
+    return best;
+}
+
+static uint4* g_in;
+static int* g_out;
+static int g_iters = 20000, g_tiles = 8192;
+template <int S> static void l_bare(int) { hipLaunchKernelGGL(bare<S>, dim3(256), dim3(256), 0, 0, g_in, g_out, g_iters); }
+template <int S, int O> static void l_loop(int) { hipLaunchKernelGGL((loop<S, O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
+
+int main()
+{
+    std::vector<unsigned> h(20 * 64 * 4, 0x01010101u);
+    hipMalloc(&g_in, h.size() * 4);
+    hipMalloc(&g_out, 4096 * 256 * 4);
+    hipMemcpy(g_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    // part 1: one 256-thread block per CU = one wave per SIMD; cycles = time * 2.4 GHz / instructions per wave
+    const char* names[4] = {"32x32x32", "16x16x64", "32x32x16 (legacy)", "16x16x32 (legacy)"};
+    float ms[4] = {run(l_bare<0>, 3), run(l_bare<1>, 3), run(l_bare<2>, 3), run(l_bare<3>, 3)};
+    for (int s = 0; s < 4; ++s)
+        std::printf("bare %-18s %8.3f ms  %.1f cycles/instruction at 2.4 GHz (constant operands, 1 wave/SIMD)\n", names[s], ms[s],
+                    ms[s] * 1e-3 * 2.4e9 / (4.0 * g_iters));
+    // part 2: random operands
+    unsigned long long st = 12345;
+    for (size_t i = 0; i < h.size(); ++i) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        h[i] = (unsigned)(st >> 32);
+    }
+    hipMemcpy(g_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        const float a2 = run(l_loop<0, 2>, 3), b2 = run(l_loop<1, 2>, 3), a1 = run(l_loop<0, 1>, 3), b1 = run(l_loop<1, 1>, 3);
+        const double pb2 = 2048.0 * 4 * g_tiles * 4, pb1 = 1024.0 * 4 * g_tiles * 4;  // 32x32 pair blocks
+        std::printf("loop random  2 waves/SIMD: 32x32x32 %.2f ms %.2f G pair-blocks/s | 16x16x64 %.2f ms %.2f G  (ratio %.3f)\n", a2,
+                    pb2 / (a2 * 1e-3) / 1e9, b2, pb2 / (b2 * 1e-3) / 1e9, a2 / b2);
+        std::printf("loop random  1 wave /SIMD: 32x32x32 %.2f ms %.2f G pair-blocks/s | 16x16x64 %.2f ms %.2f G  (ratio %.3f)\n", a1,
+                    pb1 / (a1 * 1e-3) / 1e9, b1, pb1 / (b1 * 1e-3) / 1e9, a1 / b1);
+    }
+    return 0;
+}
