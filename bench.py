@@ -9,7 +9,8 @@ D = 10^7 gen-v1 rows replicated in every GPU's HBM; the 4x10^6-query set is stre
 warmup + 3 steps = the whole query set);
 one STEP = one pass of the hot path over one batch of `--batch` mixed-type queries per GPU
 (inputs resident in HBM when the timed region starts, result ids gathered to rank 0 over RCCL
-inside the timed region when N > 1).  Queries shard across ranks with no data-path collective
+inside the timed region when N > 1).  "end_to_end" repeats the same batches from host memory to host memory
+(the reference's own timing scope, PCIe-inclusive; never `value`).  Queries shard across ranks with no data-path collective
 (weak scaling: per-GPU work is fixed).  value = queries all ranks answered / max-over-ranks time.
 
 Extra JSON objects: "roofline" for the dominant kernel (HIP-event kernel time measured live on the
@@ -42,7 +43,11 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000, help="rows of D")
     ap.add_argument("--batch", type=int, default=1048576, help="queries per step per GPU")
     ap.add_argument("--force-type", type=int, default=-1, help="-1 mixed types, 0..3 a single type")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+                    help="time cap of the CPU baseline leg (0 = skip): it times the fixed --cpu-queries prefix in chunks "
+                         "of 256 queries and stops at the first chunk boundary past the cap")
+    ap.add_argument("--cpu-queries", type=int, default=2048, help="CPU baseline sample: first N queries of the first timed batch (SURVEY 8d)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory (PCIe-inclusive) leg")
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the result gather even with one rank (rehearsal)")
@@ -78,6 +83,7 @@ def main():
     eng = pkg.Engine(local_rank)
     if a.engine:
         eng.set_engine(a.engine)
+    eng.reserve(a.batch * total_batches)                                # buffers + batch workspace before anything is timed
     t0 = time.time()
     eng.gen_data(a.n, T.SEED_DATA, T.GEN_V1, 100)                      # D replicated per GPU
     load_s = time.time() - t0
@@ -87,18 +93,19 @@ def main():
     assert q_last - q_first == a.batch * total_batches
     eng.gen_queries(a.batch * total_batches, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, first_row=q_first)
 
-    ids_dev = torch.empty((a.batch, K), dtype=torch.int32, device="cuda")
-    gathered = torch.empty((world * a.batch, K), dtype=torch.int32, device="cuda") if use_dist else None
+    # result gather (N > 1): every rank's block of ids goes to rank 0 over xGMI (RCCL gather; rank 0 alone needs the
+    # output.bin rows).  Two send buffers alternate, so a step never waits for the previous step's gather.
+    ids_dev = [torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(2)] if use_dist else None
+    gathered = ([torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(world)]
+                if use_dist and rank == 0 else None)
 
     def step(b):
         eng.query_resident(b * a.batch, a.batch, 1.0)                  # asynchronous on the library's stream
         if use_dist:
-            # the previous step's gather (RCCL's stream) ran under this step's compute; it must be done before
-            # its send buffer is overwritten
-            torch.cuda.current_stream().synchronize()
-            eng.export_results_device(b * a.batch, a.batch, ids_dev.data_ptr())
-            eng.sync()
-            dist.all_gather_into_tensor(gathered, ids_dev)             # result gather over xGMI (RCCL), asynchronous
+            buf = ids_dev[b & 1]
+            eng.export_results_device(b * a.batch, a.batch, buf.data_ptr())
+            eng.sync()                                                 # the block is complete (one host wait per step)
+            dist.gather(buf, gathered, dst=0)                          # RCCL, asynchronous on torch's stream
         else:
             eng.sync()
 
@@ -129,6 +136,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     engine_id = int(eng.last_timing().engine)
+    if use_dist and rank == 0 and world == 1:                          # --force-dist rehearsal: the gathered block is the local one
+        got = eng.download_results((total_batches - 1) * a.batch, a.batch, want_dists=False)
+        assert np.array_equal(gathered[0].cpu().numpy().view(np.uint32), got), "gathered ids differ from the local results"
+    # the first timed batch: its answers are what the parity / end-to-end legs compare against
+    first_timed_q = first_timed_ids = first_timed_dists = None
+    if rank == 0 or not a.no_e2e:
+        first_timed_q = eng.download_queries(a.warmup * a.batch, a.batch)
+        first_timed_ids, first_timed_dists = eng.download_results(a.warmup * a.batch, a.batch)
 
     out = None
     if rank == 0:
@@ -156,8 +171,8 @@ def main():
                                    f"{'mixed-type' if a.force_type < 0 else 'type-%d' % a.force_type} queries per GPU "
                                    f"from the gen-v1 4x10^6-query stream, k=100, sample_proportion=1",
                        "n": a.n, "queries_per_step_per_gpu": a.batch, "engine": engine_id,
-                       "sharding": "Q partitioned across ranks, D replicated, RCCL all_gather of ids"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                       "sharding": "Q partitioned across ranks, D replicated, RCCL gather of the ids to rank 0"},
+            "roofline": {"bound": "mfma" if engine_id in (2, 3) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": {2: "hvs_k_filter_mfma<bf16>", 3: "hvs_k_filter_mfma<int8>"}.get(engine_id, "hvs_k_scan_exact"),
                          "peak_is": {2: "dense BF16 MFMA", 3: "dense INT8 MFMA (integer ops)"}.get(engine_id, "FP32 vector"),
@@ -168,43 +183,74 @@ def main():
                          "rescored_pairs_per_query": rescored / max(a.batch * a.steps, 1),
                          # context, not the peak: a bare loop of the same MFMA chains sustains this much on random
                          # operands on this chip (DVFS; scripts/mfma_loop_lab.hip / mfma_i8_lab.hip -DLAB_RANDOM)
-                         "measured_mfma_ceiling_random_operands_tflops": {2: 1592.0, 3: 3444.0}.get(engine_id),
+                         # context, not the peak: what the filter-shaped loop (LDS fragment reads, epilogue, 2 waves/SIMD)
+                         # sustains on random operands on this chip: scripts/mfma_shape_lab.hip, 12.8 G 32x32 pair blocks/s
+                         # x 262144 op (INT8 16x16x64); BF16: scripts/mfma_loop_lab.hip
+                         "measured_loop_ceiling_random_operands_tflops": {2: 1592.0, 3: 3350.0}.get(engine_id),
                          "fallback_queries": fallback},
             "load_s": load_s,
         }
 
+    # ---- end-to-end leg: the reference's own timing scope (src/test.cpp:82-88: queries in host RAM -> ids in host
+    # RAM).  The same a.steps batches as ONE hvs_query call from ordinary (pageable) host memory through the library's
+    # pipeline (pinned staging, H2D one batch ahead, D2H under the next batch); never `value`.
+    if not a.no_e2e:
+        nq_e = a.batch * a.steps
+        q_host = eng.download_queries(a.warmup * a.batch, nq_e)
+        ids_host = np.empty((nq_e, K), np.uint32)
+        eng.query(q_host[: min(nq_e, 65536)], 1.0, want_dists=False)    # warm-up: staging slots exist afterwards
+        fence()
+        t1 = time.perf_counter()
+        eng.query(q_host, 1.0, want_dists=False, out_ids=ids_host)
+        e2e = time.perf_counter() - t1
+        tm = eng.last_timing()
+        if use_dist:
+            tt = torch.tensor([e2e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2e = float(tt.item())
+        if rank == 0:
+            out["end_to_end"] = {"value": world * nq_e / e2e, "unit": "queries/s", "ms_per_step": e2e / a.steps * 1e3,
+                                 "scope": "host RAM -> host RAM (pageable buffers), PCIe-inclusive, one hvs_query call of "
+                                          f"{nq_e} queries per GPU; D resident", "device_ms": tm.query_ms,
+                                 "headline": "value (inputs resident in HBM) is the headline; this is the reference's own scope"}
+        # the host path must return what the resident path returned
+        e2e_check = np.array_equal(ids_host[: a.batch], first_timed_ids) if first_timed_ids is not None else None
+        if rank == 0 and e2e_check is not None:
+            out["end_to_end"]["ids_identical_to_resident_path"] = bool(e2e_check)
+            assert e2e_check, "hvs_query (host path) and the resident path disagree"
+
     # ---- CPU baseline + recall leg (rank 0, N=1 only; the oracle is the checker, never the product)
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         nodes = eng.download_data(0, a.n)
-        b = a.warmup                                                   # first timed batch
         hw = os.cpu_count() or 1
-        probe = 8
-        q = eng.download_queries(b * a.batch, min(a.batch, 4096))
-        t1 = time.perf_counter()
-        T.oracle_query(nodes, q[:probe], engine="knn", part_threads=0, hw_threads=hw, run_parallel=True)
-        per_q = (time.perf_counter() - t1) / probe
-        m = int(max(probe, min(q.shape[0], a.cpu_seconds / max(per_q, 1e-6))))
-        t1 = time.perf_counter()
-        ref_ids, _ = T.oracle_query(nodes, q[:m], engine="knn", part_threads=0, hw_threads=hw, run_parallel=True)
-        cpu_s = time.perf_counter() - t1
-        sn = a.n
-        threads = max(1, min(hw, sn // 100000))                         # optimized_parallel.hpp:76-77
-        out["cpu_baseline"] = {"value": m / cpu_s, "unit": "queries/s", "cores": threads, "kind": "port",
-                               "sample": f"first {m} queries of the first timed batch, full D={a.n}; "
+        m_fixed = min(a.cpu_queries, a.batch)
+        q = first_timed_q[:m_fixed]
+        ref_parts, done, cpu_s = [], 0, 0.0
+        while done < m_fixed and cpu_s < a.cpu_seconds:                  # fixed prefix, in chunks of 256, capped in time
+            m = min(256, m_fixed - done)
+            t1 = time.perf_counter()
+            r_ids, _ = T.oracle_query(nodes, q[done:done + m], engine="knn", part_threads=0, hw_threads=hw, run_parallel=True)
+            cpu_s += time.perf_counter() - t1
+            ref_parts.append(r_ids)
+            done += m
+        ref_ids = np.concatenate(ref_parts)
+        threads = max(1, min(hw, a.n // 100000))                        # optimized_parallel.hpp:76-77
+        out["cpu_baseline"] = {"value": done / cpu_s, "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": f"first {done} queries of the fixed {m_fixed}-query prefix of the first timed batch "
+                                         f"(SURVEY 8d; chunks of 256 until {a.cpu_seconds:.0f} s), full D={a.n}; "
                                          f"reference-faithful D-partitioned Knn engine (oracle), host has {hw} cpus"}
-        got, got_d = eng.download_results(b * a.batch, m)
-        can_ids, _ = T.oracle_query(nodes, q[:m], engine="canonical", threads=hw)
-        st = T.check_parity(nodes, q[:m], got, can_ids, got_dists=got_d)
-        T.check_parity(nodes, q[:m], got, ref_ids)
-        out["recall_at_100"] = 1.0
+        got, got_d = first_timed_ids[:done], first_timed_dists[:done]
+        can_ids, _ = T.oracle_query(nodes, q[:done], engine="canonical", threads=hw)
+        st = T.check_parity(nodes, q[:done], got, can_ids, got_dists=got_d)
+        T.check_parity(nodes, q[:done], got, ref_ids)
+        hits = sum(len(np.intersect1d(got[i], can_ids[i])) for i in range(done))
+        out["recall_at_100"] = hits / (100.0 * done)                    # computed; ties at rank 100 are the only slack
+        out["recall_checked_queries"] = done
         out["parity"] = st
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if use_dist and rank == 0 and world == 1:
-        got = eng.download_results((total_batches - 1) * a.batch, a.batch, want_dists=False)
-        assert np.array_equal(gathered.cpu().numpy().view(np.uint32), got), "gathered ids differ from the local results"
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -54,12 +54,38 @@ typedef struct hvs_timing {
     uint32_t engine;      /* engine that ran                                                        */
     uint32_t fallback_queries; /* queries re-run by the exact scan after a filter overflow          */
     uint64_t rescored_pairs;   /* MFMA engine: (query,row) pairs handed to the exact re-scoring kernel */
+    uint32_t n_gpus;      /* GPUs that took part (multi-GPU context: query_ms = the slowest GPU's, counters summed)   */
+    uint32_t reserved;
+    double host_ms;       /* last hvs_query: wall time of the whole call, host memory in -> host memory out (the
+                             reference's timing scope, src/test.cpp:82-88); 0 for the device-resident calls          */
 } hvs_timing;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 
-/* device < 0: use the calling thread's current HIP device. */
+/* One GPU.  device < 0: use the calling thread's current HIP device. */
 int hvs_create(hvs_ctx **out, int device);
+/* All GPUs of the node behind ONE context -- what the reference's vec_query does with the cores of the machine
+ * (optimized_parallel.hpp:73-89: it sizes and owns its worker pool itself).  n_gpus = 0: every visible GPU.  D is
+ * replicated (one upload over PCIe, GPU-to-GPU copies over xGMI), the queries of a call are cut into one contiguous
+ * range per GPU (optimized_parallel.hpp:91: iterations are independent), one host thread drives each GPU, and every GPU
+ * writes its block of ids straight into its slice of the caller's out_ids -- no collective.  Every function below
+ * accepts such a context unless it says "single-GPU contexts only". */
+int hvs_create_multi(hvs_ctx **out, int n_gpus);
+/* The same on an explicit device list; an index may repeat ("virtual ranks": several parts on one GPU -- how the
+ * multi-GPU plan is tested on a one-GPU box). */
+int hvs_create_on_devices(hvs_ctx **out, const int *devices, int n);
+int hvs_num_gpus(const hvs_ctx *ctx);
+/* GPUs visible to this process (0 when there is none: the library has no CPU fallback). */
+int hvs_device_count(void);
+/* How hvs_query of a multi-GPU context brings the ids home.  DIRECT (default): each GPU's pipeline D2H-copies into its
+ * slice of the caller's array.  PEER: the blocks travel GPU -> GPU 0 over xGMI and leave in one D2H (A/B partner; a
+ * process-per-GPU driver gathers with RCCL instead, bench.py / sharding.py). */
+#define HVS_GATHER_DIRECT 0
+#define HVS_GATHER_PEER 1
+int hvs_set_gather(hvs_ctx *ctx, int mode);
+/* Announce the size of the coming calls: query/result buffers and the per-batch workspace (~17 GB for batches of 2^20
+ * queries) are allocated now (and again after a later hvs_load_data) instead of inside the first query. */
+int hvs_reserve(hvs_ctx *ctx, uint32_t nq);
 void hvs_destroy(hvs_ctx *ctx);
 /* Message of the last failing call on this context ("" if none). Valid until the next call. */
 const char *hvs_last_error(const hvs_ctx *ctx);
@@ -99,6 +125,9 @@ uint32_t hvs_num_rows(const hvs_ctx *ctx);
  * distances of those ids, or NULL.  sample_proportion as in the reference: rows [0, sn) are
  * searched with sn = uint32(float(sample_proportion) * float(n)) (optimized_parallel.hpp:67);
  * padding ids come from the end of the full set (n-1, n-2, ...), optimized_parallel.hpp:149-157.
+ * The call is a pipeline: queries go to the GPU in pieces through pinned staging slots one batch ahead of the engine,
+ * finished batches' ids come back while the next batch computes (buffers the caller pinned itself skip the staging
+ * copies).  hvs_last_timing().host_ms is the wall time of the whole call.
  */
 int hvs_query(hvs_ctx *ctx, const float *q_rows, uint32_t nq, float sample_proportion, uint32_t *out_ids,
               float *out_dists);
@@ -110,12 +139,13 @@ int hvs_gen_queries(hvs_ctx *ctx, uint32_t nq, uint64_t seed, int profile, uint3
                     uint64_t first_row);
 int hvs_download_queries(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float *out_rows);
 /* Answer resident queries [q0, q0+nq); results stay on the device (rows q0..q0+nq of the result
- * buffer).  Asynchronous on the context stream; hvs_sync waits. */
+ * buffer).  Asynchronous on the context stream(s); hvs_sync waits (and lets the exact engine re-run the few queries
+ * whose filter lists overflowed, if any). */
 int hvs_query_resident(hvs_ctx *ctx, uint32_t q0, uint32_t nq, float sample_proportion);
 int hvs_sync(hvs_ctx *ctx);
 int hvs_download_results(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *out_ids, float *out_dists);
 /* Copy result rows [q0,q0+nq) into caller-owned DEVICE buffers (same GPU), e.g. a collective's
- * send buffer.  d_dists may be NULL.  Asynchronous on the context stream. */
+ * send buffer.  d_dists may be NULL.  Asynchronous on the context stream.  Single-GPU contexts only. */
 int hvs_export_results_device(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *d_ids, float *d_dists);
 /* D-sharded mode (rows partitioned over GPUs, every GPU answers all queries on its rows with hvs_set_padding(ctx, 0)):
  * merges the shards' partial answers on the device -- the multi-GPU counterpart of Knn::merge (reference
@@ -123,7 +153,8 @@ int hvs_export_results_device(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *
  * d_ids_all / d_dists_all: DEVICE, [nshards][nq][100] as an all_gather of the per-shard results lays them out (ids
  * shard-local, 0xFFFFFFFF = empty slot); shard_row0: HOST, first global row of each shard (nshards <= 16);
  * d_pad_dists: DEVICE, [nq][100], exact-order distance of query q to row n_total-1-s; outputs: DEVICE, [nq][100], global
- * ids in ascending (dist, id) order (d_out_dists may be NULL).  Asynchronous on the context stream. */
+ * ids in ascending (dist, id) order (d_out_dists may be NULL).  Asynchronous on the context stream.  Single-GPU
+ * contexts only. */
 int hvs_merge_shards_device(hvs_ctx *ctx, uint32_t nshards, uint32_t nq, const uint32_t *d_ids_all,
                             const float *d_dists_all, const uint64_t *shard_row0, uint32_t n_total,
                             const float *d_pad_dists, uint32_t *d_out_ids, float *d_out_dists);

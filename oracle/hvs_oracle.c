@@ -111,9 +111,9 @@ static qparams parse_query(const float *q)
 {
     qparams p;
     const float t = q[0];
-    p.type = (t >= 0.0f && t < 4.0f) ? (uint32_t)t : 4u;
+    p.type = (t > -1.0f && t < 4.0f) ? (uint32_t)(int32_t)t : 4u; /* uint32(-0.5f) == 0: defined, type 0 */
     const float v = q[1];
-    if (v > -2147483648.0f && v < 2147483648.0f) {
+    if (v >= -2147483648.0f && v < 2147483648.0f) { /* int32(-2^31) is INT_MIN: defined */
         p.vf = (float)(int32_t)v;
     } else {
         p.vf = 0.0f;
@@ -152,9 +152,30 @@ typedef struct {
     uint32_t id;
 } cand;
 
+/* Canonical order (dist asc, id asc) as a TOTAL order on the distance bits: distances are sums of squares (>= +0), so
+ * their bit patterns order like the values; +inf follows every finite value and NaN -- one canonical pattern, x86 and
+ * gfx950 produce different ones -- follows +inf.  The reference admits any row while its list is not full
+ * (optimized_impl.h:301-304) and then calls std::sort, whose result for NaN keys is unspecified: for NaN this order is
+ * the build's own choice, for +inf it is the canonical rule. */
+static inline uint32_t dist_bits(float d)
+{
+    uint32_t u;
+    if (d != d) return 0x7FC00000u;
+    memcpy(&u, &d, 4);
+    return u;
+}
+static inline float canon_nan(float d)
+{
+    const uint32_t u = dist_bits(d);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 static inline int cand_less(const cand *a, const cand *b)
 {
-    return a->d < b->d || (a->d == b->d && a->id < b->id);
+    const uint32_t ua = dist_bits(a->d), ub = dist_bits(b->d);
+    return ua < ub || (ua == ub && a->id < b->id);
 }
 
 static int cand_cmp(const void *a, const void *b)
@@ -239,7 +260,7 @@ static void one_query_canonical(const float *nodes, uint32_t n, uint32_t sn, con
     qsort(heap, KNN, sizeof(cand), cand_cmp);
     for (int k = 0; k < KNN; ++k) {
         out_ids[k] = heap[k].id;
-        if (out_dists) out_dists[k] = heap[k].d;
+        if (out_dists) out_dists[k] = canon_nan(heap[k].d);
     }
 }
 
@@ -506,8 +527,8 @@ void hvs_oracle_dists_for_ids(const float *nodes, const float *queries, uint32_t
 {
     for (uint32_t i = 0; i < nq; ++i)
         for (int k = 0; k < KNN; ++k)
-            out[(size_t)i * KNN + k] = hvs_oracle_dist_simd_order(
-                nodes + (size_t)ids[(size_t)i * KNN + k] * DCOLS + 2, queries + (size_t)i * QCOLS + 4);
+            out[(size_t)i * KNN + k] = canon_nan(hvs_oracle_dist_simd_order(
+                nodes + (size_t)ids[(size_t)i * KNN + k] * DCOLS + 2, queries + (size_t)i * QCOLS + 4));
 }
 
 /* ------------------------------------------------------------------------- *

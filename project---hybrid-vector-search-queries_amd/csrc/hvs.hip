@@ -9,8 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -68,6 +71,7 @@ struct hvs_ctx {
     int tile_fmt = HVS_FMT_NONE;                          // format of the tiles currently built
     int planned_fmt = HVS_FMT_BF16;                       // what HVS_ENGINE_AUTO uses for this data set
     bool i8_usable = false;
+    bool i8_rejected = false;  // the INT8 tiles were built and their bound was unusable: do not try again
     double index_ms = 0.0;
     // ... and per-batch state
     HvsBatch fb{};
@@ -78,11 +82,37 @@ struct hvs_ctx {
     uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
 
     hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;
-    static constexpr int kMaxLaunchEvents = 64;
-    hipEvent_t ev_k0[kMaxLaunchEvents], ev_k1[kMaxLaunchEvents];
-    int n_launch_events = 0;
+    // start/stop event pairs around the dominant kernel's launches of the current call (grown on demand: a call
+    // of 10^7 queries is 10 batches x 14 levels)
+    std::vector<hipEvent_t> ev_k;
+    int n_launch_events = 0;  // pairs used by the current call
     bool timing_valid = false;
     hvs_timing timing{};
+    double host_ms = 0.0;     // wall time of the last hvs_query (host memory in -> host memory out)
+
+    // queries whose candidate lists overflowed, collected over all batches of a call; the exact engine re-runs them
+    // when the call's results are first needed (resolve_overflow) -- no host synchronisation inside a batch
+    uint32_t* h_ovf = nullptr;  // pinned
+    bool ovf_pending = false;
+    uint32_t pend_sn = 0;
+
+    // host <-> device pipeline of hvs_query: copy streams + rings of pinned staging slots
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    static constexpr uint32_t kStageQ = 65536;  // queries per staging slot
+    static constexpr int kRing = 4;
+    float* h_in[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* h_out_ids[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    float* h_out_dists[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_out[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_batch = nullptr, ev_stage = nullptr;
+    uint32_t reserve_nq = 0;  // hvs_reserve: queries per call the caller announced
+
+    // multi-GPU root (hvs_create_multi): owns one leaf context per GPU; D is replicated, the queries of a call are cut
+    // into one contiguous range per leaf (optimized_parallel.hpp:91: iterations are independent) and every leaf
+    // writes its block of ids straight into its slice of the caller's buffer
+    std::vector<hvs_ctx*> kids;
+    std::vector<uint32_t> kid_q0;  // resident queries: first global index of each leaf's range (kids.size() + 1 entries)
+    int gather_mode = 0;           // HVS_GATHER_DIRECT / HVS_GATHER_PEER
 };
 
 namespace {
@@ -133,6 +163,26 @@ int dev_alloc(hvs_ctx* c, T** p, size_t count)
     return HVS_OK;
 }
 
+// Event pair around one launch of the dominant kernel (HIP events on the library's own stream: bench.py's roofline
+// reads their sum).  begin returns the pair's index or -1 (events could not be created: the launch goes untimed).
+int kernel_timer_begin(hvs_ctx* c)
+{
+    const size_t need = 2u * (size_t)(c->n_launch_events + 1);
+    while (c->ev_k.size() < need) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        c->ev_k.push_back(e);
+    }
+    const int ev = c->n_launch_events;
+    if (hipEventRecord(c->ev_k[2 * ev], c->stream) != hipSuccess) return -1;
+    return ev;
+}
+void kernel_timer_end(hvs_ctx* c, int ev)
+{
+    if (ev < 0) return;
+    if (hipEventRecord(c->ev_k[2 * ev + 1], c->stream) == hipSuccess) c->n_launch_events = ev + 1;
+}
+
 // optimized_parallel.hpp:67: const uint32_t sn = uint32_t(sample_proportion * n);  (float product)
 uint32_t sample_rows(float sample_proportion, uint32_t n)
 {
@@ -149,6 +199,7 @@ int ensure_results(hvs_ctx* c, uint32_t nq)
     int rc;
     if ((rc = dev_alloc(c, &c->d_out_ids, (size_t)nq * HVS_KNN))) return rc;
     if ((rc = dev_alloc(c, &c->d_out_dists, (size_t)nq * HVS_KNN))) return rc;
+    if ((rc = dev_alloc(c, &c->d_ovf_list, (size_t)nq))) return rc;
     c->res_cap = nq;
     return HVS_OK;
 }
@@ -230,8 +281,7 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
     }
     HVS_HIP(c, hipMemsetAsync(c->d_cand_cnt, 0, (size_t)p.nq_pad * p.nchunks * sizeof(uint32_t), c->stream));
 
-    const int ev = (record_events && c->n_launch_events < hvs_ctx::kMaxLaunchEvents) ? c->n_launch_events : -1;
-    if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+    const int ev = record_events ? kernel_timer_begin(c) : -1;
     if (sn > 0) {
         unsigned long long* stat = count_stats ? c->d_counters : c->d_counters + 4;
         const dim3 grid(p.nq_pad / 256u, p.nchunks);
@@ -251,10 +301,7 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
                                    p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
         }
     }
-    if (ev >= 0) {
-        HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
-        c->n_launch_events++;
-    }
+    kernel_timer_end(c, ev);
     if (c->scalar_order)
         hipLaunchKernelGGL(hvs_k_select<true>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
                            qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
@@ -282,6 +329,7 @@ void free_index(hvs_ctx* c)
     c->have_index = false;
     c->tile_fmt = HVS_FMT_NONE;
     c->i8_usable = false;
+    c->i8_rejected = false;
 }
 
 // Planner of HVS_ENGINE_AUTO: which tile format filters this data set more cheaply.  The INT8 filter does
@@ -466,9 +514,12 @@ int build_index(hvs_ctx* c)
         free_index(c);
         return rc;
     }
-    if (!c->have_index && HVS_IS_I8(fmt) && (rc = build_tiles(c, HVS_FMT_BF16))) {
-        free_index(c);
-        return rc;
+    if (!c->have_index && HVS_IS_I8(fmt)) {
+        c->i8_rejected = true;
+        if ((rc = build_tiles(c, HVS_FMT_BF16))) {
+            free_index(c);
+            return rc;
+        }
     }
     if (!c->have_index) free_index(c);  // neither format has a usable bound: exact engine only
     return HVS_OK;
@@ -510,9 +561,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
         HVS_A(paircnt, groups);
         HVS_A(goverflow, groups);
 #undef HVS_A
-        if ((rc = dev_alloc(c, &c->d_ovf_list, (size_t)slots))) return rc;
         if (!c->d_layout) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_layout), 16 * sizeof(uint32_t)));
-        if (!c->d_ovf_count) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), sizeof(uint32_t)));
         c->fb_slots_cap = slots;
     }
     B.nslots = slots;
@@ -526,27 +575,27 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
 
 // slot layout, position ranges, norms and B fragments of one batch (shared by the MFMA engine and the
 // range-based exact engine)
-int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt)
+int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt, bool host_counts = false)
 {
     int rc = ensure_filter_workspace(c, nqb);
     if (rc) return rc;
     HvsBatch& B = c->fb;
     const uint32_t n = c->n;
     // ~4096 queries of a predicate class per start-position bin (32 groups); inside a bin queries are
-    // ordered by range end, so the 4 groups of a filter workgroup stream nearly the same run of tiles
+    // ordered by range end, so the 4 groups of a filter workgroup stream nearly the same run of tiles.  The class
+    // populations stay on the device (hvs_k_query_keys2 reads them there); only the range-scan exact engine, whose
+    // launch shapes depend on them, waits for a copy (`host_counts`).
     HVS_HIP(c, hipMemsetAsync(c->d_layout + 8, 0, 8 * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(hvs_k_count_classes, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
                        c->d_layout + 8);
-    uint32_t counts[5] = {0, 0, 0, 0, 0};
-    HVS_HIP(c, hipMemcpyAsync(counts, c->d_layout + 8, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    HvsBins bins;
-    for (int k = 0; k < 5; ++k) {
-        bins.nbins[k] = std::max(1u, std::min(4096u, counts[k] / 4096u));
-        c->class_counts[k] = counts[k];
+    if (host_counts) {
+        uint32_t counts[5] = {0, 0, 0, 0, 0};
+        HVS_HIP(c, hipMemcpyAsync(counts, c->d_layout + 8, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 5; ++k) c->class_counts[k] = counts[k];
     }
     hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys_ct,
-                       c->d_keys_t, n, bins, c->d_keys, c->d_qidx);
+                       c->d_keys_t, n, c->d_layout + 8, c->d_keys, c->d_qidx);
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                          (size_t)nqb, 0, 64, c->stream));
@@ -567,7 +616,7 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt)
 // streaming all of them (8.2 k vs 14 k queries/s).
 int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 {
-    int rc = prep_batch(c, q0, nqb, sn == c->n, HVS_FMT_BF16);  // (the range scan uses the ranges only)
+    int rc = prep_batch(c, q0, nqb, sn == c->n, HVS_FMT_BF16, true);  // (the range scan uses the ranges only)
     if (rc) return rc;
     HvsBatch& B = c->fb;
     if (sn != c->n)
@@ -593,8 +642,7 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         c->cand_lists = lists;
     }
     HVS_HIP(c, hipMemsetAsync(c->d_cand_cnt, 0, lists * sizeof(uint32_t), c->stream));
-    const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
-    if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+    const int ev = kernel_timer_begin(c);
     const dim3 grid((slot_end + 255u) / 256u, nchunks);
     if (c->scalar_order)
         hipLaunchKernelGGL(hvs_k_scan_ranges<true>, grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
@@ -602,10 +650,7 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     else
         hipLaunchKernelGGL(hvs_k_scan_ranges<false>, grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
                            c->d_perm_t, nchunks, slot_begin, slot_end, c->d_cand, c->d_cand_cnt, c->d_counters);
-    if (ev >= 0) {
-        HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
-        c->n_launch_events++;
-    }
+    kernel_timer_end(c, ev);
     const uint32_t nsel = slot_end - slot_begin;
     uint64_t* cand = c->d_cand + (size_t)slot_begin * HVS_CAND_CAP;
     uint32_t* cnt = c->d_cand_cnt + slot_begin;
@@ -660,8 +705,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
         for (uint32_t level = level0; level <= level1; ++level) {
             const uint32_t count = L.off[level + 1] - L.off[level];
-            const int ev = c->n_launch_events < hvs_ctx::kMaxLaunchEvents ? c->n_launch_events : -1;
-            if (ev >= 0) HVS_HIP(c, hipEventRecord(c->ev_k0[ev], c->stream));
+            const int ev = kernel_timer_begin(c);
             const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
             if (fmt == HVS_FMT_I8X16)
                 hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,
@@ -672,10 +716,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
             else
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_BF16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
                                    c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
-            if (ev >= 0) {
-                HVS_HIP(c, hipEventRecord(c->ev_k1[ev], c->stream));
-                c->n_launch_events++;
-            }
+            kernel_timer_end(c, ev);
         }
         if (fmt == HVS_FMT_I8X16)
             hipLaunchKernelGGL(hvs_k_rescore<true>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
@@ -685,29 +726,50 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
                                sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_counters);
         launch_merge(level1 == L.K);
     }
-    // queries whose candidate lists overflowed are answered again by the exact engine
-    HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+    // queries whose candidate lists overflowed go on the call's list; the exact engine answers them again when the
+    // call's results are first needed (resolve_overflow) -- the batch itself never waits for the host
     hipLaunchKernelGGL(hvs_k_collect_overflow, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, B, c->d_ovf_list,
                        c->d_ovf_count);
     HVS_HIP(c, hipGetLastError());
-    uint32_t novf = 0;
-    HVS_HIP(c, hipMemcpyAsync(&novf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    if (novf) {
-        c->fallback_queries += novf;
-        for (uint32_t off = 0; off < novf; off += kBatch) {
-            const uint32_t m = std::min(kBatch, novf - off);
-            if ((rc = run_batch_exact(c, 0, m, sn, c->d_ovf_list + off, false, false))) return rc;
-        }
-    }
     return HVS_OK;
 }
 
-int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
+// The exact engine re-runs the queries whose filter lists overflowed (rare: thousands of equal distances, queries
+// outside the data's bounding box, non-finite components).  Called wherever a call's results or timing leave the
+// library; costs one stream synchronisation per call.
+int resolve_overflow(hvs_ctx* c)
+{
+    if (!c->ovf_pending) return HVS_OK;
+    HVS_HIP(c, hipSetDevice(c->device));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->ovf_pending = false;
+    const uint32_t novf = *c->h_ovf;
+    if (novf == 0u) return HVS_OK;
+    c->fallback_queries = novf;
+    c->timing.fallback_queries = novf;
+    for (uint32_t off = 0; off < novf; off += kBatch) {
+        const uint32_t m = std::min(kBatch, novf - off);
+        int rc = run_batch_exact(c, 0, m, c->pend_sn, c->d_ovf_list + off, false, false);
+        if (rc) return rc;
+    }
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));  // the fallback belongs to the call's device time
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+// `after_batch(off, nqb)`: called after the kernels of each batch have been enqueued (the host pipeline of hvs_query
+// hangs its copies there); queries [q0 + off, q0 + off + nqb) are complete on the stream at that point, except for
+// overflowed ones (resolve_overflow)
+template <typename AfterBatch>
+int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, AfterBatch after_batch)
 {
     if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
     if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
     HVS_HIP(c, hipSetDevice(c->device));
+    {
+        int rc = resolve_overflow(c);  // an earlier call whose results were never fetched
+        if (rc) return rc;
+    }
     const uint32_t sn = sample_rows(sample_proportion, c->n);
     // The index orders ALL rows: with a sampled prefix [0,sn) the filter still proposes rows >= sn and the
     // exact stages drop them, so its candidate lists grow by n/sn -- used down to sn = n/4, below that
@@ -718,13 +780,17 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     if (mfma) {
         // the tiles exist in one format at a time: an engine choice made after the load rebuilds them
         int want = c->engine == HVS_ENGINE_MFMA_FILTER ? HVS_FMT_BF16
-                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable ? kI8Fmt : HVS_FMT_BF16)
+                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable && !c->i8_rejected ? kI8Fmt : HVS_FMT_BF16)
                                                        : c->planned_fmt;
+        if (HVS_IS_I8(want) && c->i8_rejected) want = HVS_FMT_BF16;
         if (want != c->tile_fmt) {
             const int had = c->tile_fmt;
             int rc = build_tiles(c, want);
             if (rc) return rc;
-            if (!c->have_index && (rc = build_tiles(c, had))) return rc;  // no usable bound in that format
+            if (!c->have_index) {  // no usable bound in that format: remember it, go back
+                if (HVS_IS_I8(want)) c->i8_rejected = true;
+                if ((rc = build_tiles(c, had))) return rc;
+            }
             if (!c->have_index) return fail(c, HVS_ESTATE, "internal: tile rebuild lost the index");
         }
     }
@@ -732,6 +798,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
     c->n_launch_events = 0;
     c->fallback_queries = 0;
     HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
     const uint32_t step = mfma ? kBatchMfma : kBatch;
@@ -740,31 +807,32 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
         int rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
                       : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
         if (rc) return rc;
+        if ((rc = after_batch(off, nqb))) return rc;
     }
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    if (mfma) {
+        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        c->ovf_pending = true;
+        c->pend_sn = sn;
+    }
     c->timing = hvs_timing{};
     c->timing.nq = nq;
     c->timing.engine = mfma ? (HVS_IS_I8(c->tile_fmt) ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
-    c->timing.fallback_queries = c->fallback_queries;
+    c->timing.n_gpus = 1;
     c->timing_valid = true;
     return HVS_OK;
 }
 
-}  // namespace
+// ---------------------------------------------------------------------------------------------
+// leaf (one GPU) implementations of the C ABI; the multi-GPU root dispatches to them
+// ---------------------------------------------------------------------------------------------
+struct NoHook {
+    int operator()(uint32_t, uint32_t) const { return HVS_OK; }
+};
 
-extern "C" {
-
-const char* hvs_version(void) { return "hvs-mi355x 0.1 (gfx950)"; }
-
-const char* hvs_last_global_error(void) { return g_global_err.c_str(); }
-
-int hvs_create(hvs_ctx** out, int device)
+int leaf_create(hvs_ctx** out, int device)
 {
-    if (!out) {
-        g_global_err = "hvs_create: out is NULL";
-        return HVS_EINVAL;
-    }
     *out = nullptr;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -792,29 +860,35 @@ int hvs_create(hvs_ctx** out, int device)
         return HVS_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
-        return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev_q0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_q1)) != hipSuccess) return bail("hipEventCreate", e);
-    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
-        c->ev_k0[i] = c->ev_k1[i] = nullptr;
-    }
-    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
-        if ((e = hipEventCreate(&c->ev_k0[i])) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreate(&c->ev_k1[i])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_batch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (int i = 0; i < hvs_ctx::kRing; ++i) {
+        if ((e = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_layout), 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ovf), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+    *c->h_ovf = 0u;
     *out = c;
     return HVS_OK;
 }
 
-void hvs_destroy(hvs_ctx* c)
+void leaf_destroy(hvs_ctx* c)
 {
-    if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_data, c->d_q,      c->d_out_ids,  c->d_out_dists, c->d_keys,    c->d_keys_sorted,
+    if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+    if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+    void* ptrs[] = {c->d_data, c->d_q,      c->d_out_ids,  c->d_out_dists, c->d_keys,     c->d_keys_sorted,
                     c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -827,69 +901,59 @@ void hvs_destroy(hvs_ctx* c)
         for (void* p : fp)
             if (p) (void)hipFree(p);
     }
+    if (c->h_ovf) (void)hipHostFree(c->h_ovf);
+    for (int i = 0; i < hvs_ctx::kRing; ++i) {
+        if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
+        if (c->h_out_ids[i]) (void)hipHostFree(c->h_out_ids[i]);
+        if (c->h_out_dists[i]) (void)hipHostFree(c->h_out_dists[i]);
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
+    if (c->ev_batch) (void)hipEventDestroy(c->ev_batch);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_q0) (void)hipEventDestroy(c->ev_q0);
     if (c->ev_q1) (void)hipEventDestroy(c->ev_q1);
-    for (int i = 0; i < hvs_ctx::kMaxLaunchEvents; ++i) {
-        if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
-        if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
-    }
+    for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
 }
 
-const char* hvs_last_error(const hvs_ctx* c) { return c ? c->err.c_str() : "hvs: NULL context"; }
-
-int hvs_set_engine(hvs_ctx* c, int engine)
+// query / result buffers and the batch workspace for calls of up to nq queries (hvs_reserve, hvs_query): keeps the
+// ~17 GB of per-batch state of a 2^20-query batch out of the first query's own time
+int leaf_reserve(hvs_ctx* c, uint32_t nq)
 {
-    if (!c) return HVS_EINVAL;
-    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER &&
-        engine != HVS_ENGINE_MFMA_I8)
-        return fail(c, HVS_EINVAL, "hvs_set_engine: unknown engine");
-    c->engine = engine;
-    if (c->d_data && !c->have_index &&
-        (engine == HVS_ENGINE_MFMA_FILTER || engine == HVS_ENGINE_MFMA_I8 || c->n >= kIndexMinRows)) {
-        HVS_HIP(c, hipSetDevice(c->device));
-        return build_index(c);
-    }
-    return HVS_OK;
+    HVS_HIP(c, hipSetDevice(c->device));
+    c->reserve_nq = std::max(c->reserve_nq, nq);
+    if (nq == 0u) return HVS_OK;
+    int rc = ensure_queries(c, nq);
+    if (rc) return rc;
+    if (c->have_index) return ensure_filter_workspace(c, std::min(nq, kBatchMfma));
+    const uint32_t nqb = std::min(nq, kBatch);
+    return ensure_batch_workspace(c, nqb, make_plan(nqb, c->n ? c->n : 1u));
 }
 
-int hvs_set_padding(hvs_ctx* c, int enabled)
-{
-    if (!c) return HVS_EINVAL;
-    c->padding = enabled != 0;
-    return HVS_OK;
-}
-
-int hvs_set_distance_order(hvs_ctx* c, int order)
-{
-    if (!c) return HVS_EINVAL;
-    if (order != HVS_ORDER_SIMD && order != HVS_ORDER_SCALAR) return fail(c, HVS_EINVAL, "hvs_set_distance_order: unknown order");
-    c->scalar_order = order == HVS_ORDER_SCALAR;
-    return HVS_OK;
-}
-
-uint32_t hvs_num_rows(const hvs_ctx* c) { return c ? c->n : 0u; }
-
-static int begin_data(hvs_ctx* c, uint32_t n)
+int begin_data(hvs_ctx* c, uint32_t n)
 {
     if (n < HVS_KNN)
         return fail(c, HVS_EINVAL,
                     "data set needs at least 100 rows (the reference pads results with rows n-1, n-2, ...)");
     HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->n = 0;
     return dev_alloc(c, &c->d_data, (size_t)n * HVS_DCOLS);
 }
 
-// upload/generation is timed by ev_q0..ev_q1; the index build (sort + BF16 tiles) follows
-static int finish_data(hvs_ctx* c)
+// upload/generation is timed by ev_q0..ev_q1; the index build (orderings + tiles) follows
+int finish_data(hvs_ctx* c)
 {
     float ms = 0.f;
     HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
     c->load_ms = ms;
     free_index(c);
-    // the index (two orderings + BF16 tiles) serves both engines: the exact engine scans position ranges
+    // the index (two orderings + tiles) serves both engines: the exact engine scans position ranges
     if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER && c->engine != HVS_ENGINE_MFMA_I8) return HVS_OK;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     int rc = build_index(c);
@@ -906,28 +970,92 @@ static int finish_data(hvs_ctx* c)
     HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
     c->index_ms = ms;
     c->load_ms += ms;
+    if (c->reserve_nq) return leaf_reserve(c, c->reserve_nq);  // the caller announced its call size (hvs_reserve)
     return HVS_OK;
 }
 
-int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+bool host_pointer_is_pinned(const void* p)
 {
-    if (!c) return HVS_EINVAL;
-    if (!rows) return fail(c, HVS_EINVAL, "hvs_load_data: rows is NULL");
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // ordinary (pageable) host memory is "invalid value" to this query
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// pinned staging slots of the host pipeline, allocated on first use (4 x (27 + 26 + 26) MB)
+int ensure_staging(hvs_ctx* c, bool dists)
+{
+    for (int i = 0; i < hvs_ctx::kRing; ++i) {
+        if (!c->h_in[i])
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_in[i]), (size_t)hvs_ctx::kStageQ * HVS_QCOLS * sizeof(float),
+                                     hipHostMallocDefault));
+        if (!c->h_out_ids[i])
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_ids[i]), (size_t)hvs_ctx::kStageQ * HVS_KNN * sizeof(uint32_t),
+                                     hipHostMallocDefault));
+        if (dists && !c->h_out_dists[i])
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_dists[i]), (size_t)hvs_ctx::kStageQ * HVS_KNN * sizeof(float),
+                                     hipHostMallocDefault));
+    }
+    return HVS_OK;
+}
+
+// H2D of rows into c->d_data (or any device buffer), from pageable or pinned host memory.  Pageable sources go
+// through the pinned ring in 27 MB pieces so that the host copy of piece i+1 overlaps the DMA of piece i
+// (reference io.h:111-136 is replaced by the caller's bulk read; this replaces the staging an H2D of pageable memory
+// would do inside the runtime, at roughly twice its rate).
+int upload_rows(hvs_ctx* c, float* dst, const float* src, size_t nfloats)
+{
+    if (nfloats == 0) return HVS_OK;
+    if (host_pointer_is_pinned(src)) {
+        HVS_HIP(c, hipMemcpyAsync(dst, src, nfloats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        return HVS_OK;
+    }
+    int rc = ensure_staging(c, false);
+    if (rc) return rc;
+    const size_t slot = (size_t)hvs_ctx::kStageQ * HVS_QCOLS;  // floats per slot
+    size_t off = 0;
+    for (int i = 0; off < nfloats; ++i, off += slot) {
+        const int k = i % hvs_ctx::kRing;
+        const size_t m = std::min(slot, nfloats - off);
+        if (i >= hvs_ctx::kRing) HVS_HIP(c, hipEventSynchronize(c->ev_in[k]));  // the slot's previous DMA is done
+        std::memcpy(c->h_in[k], src + off, m * sizeof(float));
+        HVS_HIP(c, hipMemcpyAsync(dst + off, c->h_in[k], m * sizeof(float), hipMemcpyHostToDevice, c->s_in));
+        HVS_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
+    }
+    HVS_HIP(c, hipStreamSynchronize(c->s_in));
+    return HVS_OK;
+}
+
+int leaf_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+{
     int rc = begin_data(c, n);
     if (rc) return rc;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
-    HVS_HIP(c, hipMemcpyAsync(c->d_data, rows, (size_t)n * HVS_DCOLS * sizeof(float), hipMemcpyHostToDevice,
-                              c->stream));
+    if ((rc = upload_rows(c, c->d_data, rows, (size_t)n * HVS_DCOLS))) return rc;
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->n = n;
     return finish_data(c);
 }
 
-int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
+// D replicated from another GPU's copy (xGMI peer copy; same-device contexts: a device-to-device copy)
+int leaf_load_data_from_peer(hvs_ctx* c, const hvs_ctx* src)
 {
-    if (!c) return HVS_EINVAL;
-    if (ncat == 0) return fail(c, HVS_EINVAL, "hvs_gen_data: ncat must be > 0");
+    const uint32_t n = src->n;
+    int rc = begin_data(c, n);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
+    HVS_HIP(c, hipMemcpyPeerAsync(c->d_data, c->device, src->d_data, src->device, (size_t)n * HVS_DCOLS * sizeof(float), c->stream));
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->n = n;
+    return finish_data(c);
+}
+
+int leaf_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
+{
     int rc = begin_data(c, n);
     if (rc) return rc;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
@@ -940,9 +1068,441 @@ int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t nc
     return finish_data(c);
 }
 
+int leaf_begin_queries(hvs_ctx* c, uint32_t nq)
+{
+    HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = 0;
+    return ensure_queries(c, nq);
+}
+
+int leaf_upload_queries(hvs_ctx* c, const float* q_rows, uint32_t nq)
+{
+    int rc = leaf_begin_queries(c, nq);
+    if (rc) return rc;
+    if ((rc = upload_rows(c, c->d_q, q_rows, (size_t)nq * HVS_QCOLS))) return rc;
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = nq;
+    return HVS_OK;
+}
+
+int leaf_gen_queries(hvs_ctx* c, uint32_t nq, uint64_t seed, int profile, uint32_t ncat, int force_type, uint64_t first_row)
+{
+    int rc = leaf_begin_queries(c, nq);
+    if (rc) return rc;
+    if (nq) {
+        hipLaunchKernelGGL(hvs_k_gen_queries, dim3(256 * 4), dim3(256), 0, c->stream, c->d_q, (uint64_t)nq * HVS_QCOLS,
+                           seed, profile, ncat, force_type, first_row);
+        HVS_HIP(c, hipGetLastError());
+    }
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nq = nq;
+    return HVS_OK;
+}
+
+int leaf_sync(hvs_ctx* c)
+{
+    HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+int leaf_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_ids, float* out_dists)
+{
+    if (!out_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_results: bad range");
+    int rc = leaf_sync(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipMemcpyAsync(out_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    if (out_dists)
+        HVS_HIP(c, hipMemcpyAsync(out_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
+                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    return HVS_OK;
+}
+
+// The vec_query-equivalent region with host buffers on both sides (reference src/test.cpp:82-88), pipelined:
+//   copy-in stream   pinned slot <- caller's queries (host copy), H2D, 65536 queries per piece, one BATCH ahead
+//   compute stream   the engine, batch by batch (each batch waits for its last piece's H2D)
+//   copy-out stream  D2H of a finished batch's ids (+ distances) into pinned slots while the next batch computes;
+//                    the calling thread drains the slots into the caller's arrays
+// Buffers the caller pinned itself (hipHostMalloc / hipHostRegister) skip the staging copies.  Overflowed queries
+// (rare) are re-run at the end and their rows fetched again.
+int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids, float* out_dists)
+{
+    if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
+    if (nq == 0) return HVS_OK;
+    if (!q_rows || !out_ids) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
+    const auto t_host0 = std::chrono::steady_clock::now();
+    int rc = leaf_begin_queries(c, nq);
+    if (rc) return rc;
+    if ((rc = ensure_staging(c, out_dists != nullptr))) return rc;
+    c->nq = nq;
+    const bool in_pinned = host_pointer_is_pinned(q_rows);
+    const bool out_pinned = host_pointer_is_pinned(out_ids) && (!out_dists || host_pointer_is_pinned(out_dists));
+    constexpr uint32_t SQ = hvs_ctx::kStageQ;
+    constexpr int R = hvs_ctx::kRing;
+    const uint32_t npieces = hvs_ceil_div(nq, SQ);
+
+    // --- copy-in: pieces [p0, p1) -> device
+    uint32_t in_next = 0;  // pieces enqueued so far
+    auto stage_in_until = [&](uint32_t p1) -> int {
+        for (; in_next < p1; ++in_next) {
+            const uint32_t q0 = in_next * SQ, m = std::min(SQ, nq - q0);
+            const size_t bytes = (size_t)m * HVS_QCOLS * sizeof(float);
+            float* dst = c->d_q + (size_t)q0 * HVS_QCOLS;
+            if (in_pinned) {
+                HVS_HIP(c, hipMemcpyAsync(dst, q_rows + (size_t)q0 * HVS_QCOLS, bytes, hipMemcpyHostToDevice, c->s_in));
+            } else {
+                const int k = (int)(in_next % R);
+                if (in_next >= (uint32_t)R) HVS_HIP(c, hipEventSynchronize(c->ev_in[k]));
+                std::memcpy(c->h_in[k], q_rows + (size_t)q0 * HVS_QCOLS, bytes);
+                HVS_HIP(c, hipMemcpyAsync(dst, c->h_in[k], bytes, hipMemcpyHostToDevice, c->s_in));
+                HVS_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
+            }
+        }
+        return HVS_OK;
+    };
+    // --- copy-out of queries [q0, q0 + m): D2H pieces on s_out (after `ready`), drained into the caller's arrays
+    uint32_t out_enq = 0, out_drained = 0;  // pieces (global numbering over the call)
+    auto drain_one = [&]() -> int {
+        const int k = (int)(out_drained % R);
+        HVS_HIP(c, hipEventSynchronize(c->ev_out[k]));
+        const uint32_t q0 = out_drained * SQ, m = std::min(SQ, nq - q0);
+        std::memcpy(out_ids + (size_t)q0 * HVS_KNN, c->h_out_ids[k], (size_t)m * HVS_KNN * sizeof(uint32_t));
+        if (out_dists) std::memcpy(out_dists + (size_t)q0 * HVS_KNN, c->h_out_dists[k], (size_t)m * HVS_KNN * sizeof(float));
+        ++out_drained;
+        return HVS_OK;
+    };
+    auto copy_out_until = [&](uint32_t p1) -> int {
+        for (; out_enq < p1; ++out_enq) {
+            const uint32_t q0 = out_enq * SQ, m = std::min(SQ, nq - q0);
+            const size_t nb = (size_t)m * HVS_KNN * sizeof(uint32_t);
+            if (out_pinned) {
+                HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)q0 * HVS_KNN, c->d_out_ids + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+                if (out_dists)
+                    HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)q0 * HVS_KNN, c->d_out_dists + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+                continue;
+            }
+            if (out_enq - out_drained >= (uint32_t)R) {
+                int rc2 = drain_one();
+                if (rc2) return rc2;
+            }
+            const int k = (int)(out_enq % R);
+            HVS_HIP(c, hipMemcpyAsync(c->h_out_ids[k], c->d_out_ids + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+            if (out_dists)
+                HVS_HIP(c, hipMemcpyAsync(c->h_out_dists[k], c->d_out_dists + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+            HVS_HIP(c, hipEventRecord(c->ev_out[k], c->s_out));
+        }
+        return HVS_OK;
+    };
+
+    // The first batch's queries go in, then the engine runs batch by batch.  After the kernels of batch b have been
+    // enqueued (the GPU is busy with them): batch b+1's queries are staged and sent, the results of everything BEFORE
+    // batch b are sent out and drained, and the copy-out stream is told to wait for batch b.  The host work of a batch
+    // (two staging copies, ~0.2 s per 2^20 queries) hides under the batch's own compute.
+    const uint32_t ahead = std::max(kBatch, kBatchMfma);  // an upper bound of the engine's batch size
+    auto send_input = [&](uint32_t upto_q) -> int {
+        int r2 = stage_in_until(std::min(npieces, hvs_ceil_div(std::min(nq, upto_q), SQ)));
+        if (r2) return r2;
+        HVS_HIP(c, hipEventRecord(c->ev_stage, c->s_in));
+        HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
+        return HVS_OK;
+    };
+    if ((rc = send_input(ahead))) return rc;
+    auto after_batch = [&](uint32_t off, uint32_t nqb) -> int {
+        const uint32_t done_q = off + nqb;
+        int r2;
+        if (done_q < nq && (r2 = send_input(done_q + ahead))) return r2;
+        if ((r2 = copy_out_until(off / SQ))) return r2;  // whole pieces of the batches before this one
+        HVS_HIP(c, hipEventRecord(c->ev_batch, c->stream));
+        HVS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_batch, 0));
+        return HVS_OK;
+    };
+    if ((rc = run_queries(c, 0, nq, sample_proportion, after_batch))) return rc;
+    if ((rc = copy_out_until(npieces))) return rc;
+    while (!out_pinned && out_drained < out_enq)
+        if ((rc = drain_one())) return rc;
+    HVS_HIP(c, hipStreamSynchronize(c->s_out));
+    // overflowed queries: re-run by the exact engine, their rows fetched again
+    const bool had_ovf = c->ovf_pending;
+    if ((rc = resolve_overflow(c))) return rc;
+    if (had_ovf && c->fallback_queries) {
+        const uint32_t novf = c->fallback_queries;
+        std::vector<uint32_t> list(novf);
+        HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t qi : list) {
+            HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * HVS_KNN, c->d_out_ids + (size_t)qi * HVS_KNN, HVS_KNN * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, c->stream));
+            if (out_dists)
+                HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)qi * HVS_KNN, c->d_out_dists + (size_t)qi * HVS_KNN,
+                                          HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        }
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return HVS_OK;
+}
+
+int leaf_last_timing(hvs_ctx* c, hvs_timing* out)
+{
+    if (!c->timing_valid) return fail(c, HVS_ESTATE, "no query has run yet");
+    int rc = leaf_sync(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventSynchronize(c->ev_q1));
+    float ms = 0.f;
+    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
+    c->timing.query_ms = ms;
+    double k = 0.0;
+    for (int i = 0; i < c->n_launch_events; ++i) {
+        HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_k[2 * i], c->ev_k[2 * i + 1]));
+        k += ms;
+    }
+    c->timing.main_kernel_ms = k;
+    c->timing.main_kernel_launches = (uint32_t)c->n_launch_events;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HVS_HIP(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    c->timing.pairs = h[0];
+    c->timing.scanned_pairs = h[1];
+    c->timing.rescored_pairs = h[2];
+    c->timing.fallback_queries = c->fallback_queries;
+    c->timing.host_ms = c->host_ms;
+    *out = c->timing;
+    return HVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU root
+// ---------------------------------------------------------------------------------------------
+// contiguous, balanced range of part r of `world` (the first total % world parts get one more): sharding.shard_range
+void shard_range(uint32_t total, uint32_t r, uint32_t world, uint32_t& a, uint32_t& b)
+{
+    const uint32_t base = total / world, rem = total % world;
+    a = r * base + std::min(r, rem);
+    b = a + base + (r < rem ? 1u : 0u);
+}
+
+// run fn(leaf index) on one host thread per leaf (the reference's vec_query owns its worker threads the same way,
+// optimized_parallel.hpp:82-89, threading.hpp:100-141) and return the first failure
+template <typename Fn>
+int for_each_leaf(hvs_ctx* root, Fn fn)
+{
+    const size_t N = root->kids.size();
+    std::vector<int> rcs(N, HVS_OK);
+    if (N == 1) {
+        rcs[0] = fn(0u);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(N);
+        for (size_t r = 0; r < N; ++r) th.emplace_back([&, r]() { rcs[r] = fn((uint32_t)r); });
+        for (auto& t : th) t.join();
+    }
+    for (size_t r = 0; r < N; ++r)
+        if (rcs[r] != HVS_OK) {
+            root->err = "GPU " + std::to_string(root->kids[r]->device) + " (part " + std::to_string(r) + "): " + root->kids[r]->err;
+            return rcs[r];
+        }
+    return HVS_OK;
+}
+
+// leaves that hold part of the resident range [q0, q0 + nq): fn(leaf, local q0, count, offset into the caller's range)
+template <typename Fn>
+int for_each_resident_part(hvs_ctx* root, uint32_t q0, uint32_t nq, Fn fn)
+{
+    if (root->kid_q0.size() != root->kids.size() + 1u || (uint64_t)q0 + nq > root->kid_q0.back())
+        return fail(root, HVS_EINVAL, "query range outside the resident query set");
+    return for_each_leaf(root, [&](uint32_t r) -> int {
+        const uint32_t a = std::max(q0, root->kid_q0[r]), b = std::min(q0 + nq, root->kid_q0[r + 1]);
+        if (a >= b) return HVS_OK;
+        return fn(root->kids[r], a - root->kid_q0[r], b - a, a - q0);
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hvs_version(void) { return "hvs-mi355x 0.2 (gfx950)"; }
+
+const char* hvs_last_global_error(void) { return g_global_err.c_str(); }
+
+int hvs_create(hvs_ctx** out, int device)
+{
+    if (!out) {
+        g_global_err = "hvs_create: out is NULL";
+        return HVS_EINVAL;
+    }
+    return leaf_create(out, device);
+}
+
+int hvs_create_on_devices(hvs_ctx** out, const int* devices, int n)
+{
+    if (!out || !devices || n < 1 || n > 64) {
+        g_global_err = "hvs_create_on_devices: bad argument (1..64 device indices)";
+        if (out) *out = nullptr;
+        return HVS_EINVAL;
+    }
+    *out = nullptr;
+    hvs_ctx* root = new (std::nothrow) hvs_ctx();
+    if (!root) {
+        g_global_err = "hvs_create_on_devices: out of host memory";
+        return HVS_ENOMEM;
+    }
+    root->device = devices[0];
+    for (int i = 0; i < n; ++i) {
+        hvs_ctx* leaf = nullptr;
+        const int rc = leaf_create(&leaf, devices[i]);
+        if (rc != HVS_OK) {
+            hvs_destroy(root);
+            return rc;
+        }
+        root->kids.push_back(leaf);
+    }
+    // peer access lets the replication of D and the peer gather use xGMI directly (best effort: without it the
+    // runtime stages peer copies through host memory)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (devices[i] != devices[j]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[i]);
+                    (void)hipDeviceEnablePeerAccess(devices[j], 0);
+                }
+                (void)hipGetLastError();  // "already enabled" is fine
+            }
+    (void)hipSetDevice(devices[0]);
+    *out = root;
+    return HVS_OK;
+}
+
+int hvs_create_multi(hvs_ctx** out, int n_gpus)
+{
+    if (!out) {
+        g_global_err = "hvs_create_multi: out is NULL";
+        return HVS_EINVAL;
+    }
+    *out = nullptr;
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_global_err = std::string("hvs_create_multi: no HIP device available (") + hipGetErrorString(e) +
+                       "); this library has no CPU fallback";
+        return HVS_EHIP;
+    }
+    if (n_gpus < 0 || n_gpus > count) {
+        g_global_err = "hvs_create_multi: n_gpus outside 0..visible devices";
+        return HVS_EINVAL;
+    }
+    if (n_gpus == 0) n_gpus = count;
+    std::vector<int> devs(n_gpus);
+    for (int i = 0; i < n_gpus; ++i) devs[i] = i;
+    return hvs_create_on_devices(out, devs.data(), n_gpus);
+}
+
+int hvs_num_gpus(const hvs_ctx* c) { return !c ? 0 : (c->kids.empty() ? 1 : (int)c->kids.size()); }
+
+int hvs_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+int hvs_set_gather(hvs_ctx* c, int mode)
+{
+    if (!c) return HVS_EINVAL;
+    if (mode != HVS_GATHER_DIRECT && mode != HVS_GATHER_PEER) return fail(c, HVS_EINVAL, "hvs_set_gather: unknown mode");
+    c->gather_mode = mode;
+    return HVS_OK;
+}
+
+void hvs_destroy(hvs_ctx* c)
+{
+    if (!c) return;
+    for (hvs_ctx* k : c->kids) hvs_destroy(k);
+    if (c->kids.empty()) leaf_destroy(c);
+    delete c;
+}
+
+const char* hvs_last_error(const hvs_ctx* c) { return c ? c->err.c_str() : "hvs: NULL context"; }
+
+int hvs_set_engine(hvs_ctx* c, int engine)
+{
+    if (!c) return HVS_EINVAL;
+    if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER &&
+        engine != HVS_ENGINE_MFMA_I8)
+        return fail(c, HVS_EINVAL, "hvs_set_engine: unknown engine");
+    c->engine = engine;
+    if (!c->kids.empty()) return for_each_leaf(c, [&](uint32_t r) { return hvs_set_engine(c->kids[r], engine); });
+    if (c->d_data && !c->have_index &&
+        (engine == HVS_ENGINE_MFMA_FILTER || engine == HVS_ENGINE_MFMA_I8 || c->n >= kIndexMinRows)) {
+        HVS_HIP(c, hipSetDevice(c->device));
+        return build_index(c);
+    }
+    return HVS_OK;
+}
+
+int hvs_set_padding(hvs_ctx* c, int enabled)
+{
+    if (!c) return HVS_EINVAL;
+    c->padding = enabled != 0;
+    for (hvs_ctx* k : c->kids) k->padding = c->padding;
+    return HVS_OK;
+}
+
+int hvs_set_distance_order(hvs_ctx* c, int order)
+{
+    if (!c) return HVS_EINVAL;
+    if (order != HVS_ORDER_SIMD && order != HVS_ORDER_SCALAR) return fail(c, HVS_EINVAL, "hvs_set_distance_order: unknown order");
+    c->scalar_order = order == HVS_ORDER_SCALAR;
+    for (hvs_ctx* k : c->kids) k->scalar_order = c->scalar_order;
+    return HVS_OK;
+}
+
+uint32_t hvs_num_rows(const hvs_ctx* c) { return !c ? 0u : (c->kids.empty() ? c->n : c->kids[0]->n); }
+
+int hvs_reserve(hvs_ctx* c, uint32_t nq)
+{
+    if (!c) return HVS_EINVAL;
+    if (c->kids.empty()) return leaf_reserve(c, nq);
+    const uint32_t N = (uint32_t)c->kids.size();
+    return for_each_leaf(c, [&](uint32_t r) { return leaf_reserve(c->kids[r], hvs_ceil_div(nq, N)); });
+}
+
+int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+{
+    if (!c) return HVS_EINVAL;
+    if (!rows) return fail(c, HVS_EINVAL, "hvs_load_data: rows is NULL");
+    if (c->kids.empty()) return leaf_load_data(c, rows, n);
+    // one upload over PCIe, then every other GPU takes its copy of D from the first over xGMI and builds its own index
+    int rc = leaf_load_data(c->kids[0], rows, n);
+    if (rc) return fail(c, rc, c->kids[0]->err);
+    if (c->kids.size() == 1) return HVS_OK;
+    return for_each_leaf(c, [&](uint32_t r) { return r == 0u ? HVS_OK : leaf_load_data_from_peer(c->kids[r], c->kids[0]); });
+}
+
+int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
+{
+    if (!c) return HVS_EINVAL;
+    if (ncat == 0) return fail(c, HVS_EINVAL, "hvs_gen_data: ncat must be > 0");
+    if (c->kids.empty()) return leaf_gen_data(c, n, seed, profile, ncat);
+    return for_each_leaf(c, [&](uint32_t r) { return leaf_gen_data(c->kids[r], n, seed, profile, ncat); });
+}
+
 int hvs_download_data(hvs_ctx* c, uint32_t row0, uint32_t nrows, float* out_rows)
 {
     if (!c) return HVS_EINVAL;
+    if (!c->kids.empty()) {
+        const int rc = hvs_download_data(c->kids[0], row0, nrows, out_rows);
+        return rc ? fail(c, rc, c->kids[0]->err) : HVS_OK;
+    }
     if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded");
     if (!out_rows || (uint64_t)row0 + nrows > c->n) return fail(c, HVS_EINVAL, "hvs_download_data: bad range");
     HVS_HIP(c, hipSetDevice(c->device));
@@ -956,17 +1516,13 @@ int hvs_upload_queries(hvs_ctx* c, const float* q_rows, uint32_t nq)
 {
     if (!c) return HVS_EINVAL;
     if (!q_rows && nq) return fail(c, HVS_EINVAL, "hvs_upload_queries: q_rows is NULL");
-    HVS_HIP(c, hipSetDevice(c->device));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    c->nq = 0;
-    int rc = ensure_queries(c, nq);
-    if (rc) return rc;
-    if (nq)
-        HVS_HIP(c, hipMemcpyAsync(c->d_q, q_rows, (size_t)nq * HVS_QCOLS * sizeof(float), hipMemcpyHostToDevice,
-                                  c->stream));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    c->nq = nq;
-    return HVS_OK;
+    if (c->kids.empty()) return leaf_upload_queries(c, q_rows, nq);
+    const uint32_t N = (uint32_t)c->kids.size();
+    c->kid_q0.assign(N + 1u, 0u);
+    for (uint32_t r = 0; r < N; ++r) shard_range(nq, r, N, c->kid_q0[r], c->kid_q0[r + 1]);
+    return for_each_leaf(c, [&](uint32_t r) {
+        return leaf_upload_queries(c->kids[r], q_rows + (size_t)c->kid_q0[r] * HVS_QCOLS, c->kid_q0[r + 1] - c->kid_q0[r]);
+    });
 }
 
 int hvs_gen_queries(hvs_ctx* c, uint32_t nq, uint64_t seed, int profile, uint32_t ncat, int force_type,
@@ -974,24 +1530,22 @@ int hvs_gen_queries(hvs_ctx* c, uint32_t nq, uint64_t seed, int profile, uint32_
 {
     if (!c) return HVS_EINVAL;
     if (ncat == 0 || force_type > 3) return fail(c, HVS_EINVAL, "hvs_gen_queries: bad ncat / force_type");
-    HVS_HIP(c, hipSetDevice(c->device));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    c->nq = 0;
-    int rc = ensure_queries(c, nq);
-    if (rc) return rc;
-    if (nq) {
-        hipLaunchKernelGGL(hvs_k_gen_queries, dim3(256 * 4), dim3(256), 0, c->stream, c->d_q, (uint64_t)nq * HVS_QCOLS,
-                           seed, profile, ncat, force_type, first_row);
-        HVS_HIP(c, hipGetLastError());
-    }
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    c->nq = nq;
-    return HVS_OK;
+    if (c->kids.empty()) return leaf_gen_queries(c, nq, seed, profile, ncat, force_type, first_row);
+    const uint32_t N = (uint32_t)c->kids.size();
+    c->kid_q0.assign(N + 1u, 0u);
+    for (uint32_t r = 0; r < N; ++r) shard_range(nq, r, N, c->kid_q0[r], c->kid_q0[r + 1]);
+    return for_each_leaf(c, [&](uint32_t r) {
+        return leaf_gen_queries(c->kids[r], c->kid_q0[r + 1] - c->kid_q0[r], seed, profile, ncat, force_type, first_row + c->kid_q0[r]);
+    });
 }
 
 int hvs_download_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float* out_rows)
 {
     if (!c) return HVS_EINVAL;
+    if (!c->kids.empty())
+        return for_each_resident_part(c, q0, nq, [&](hvs_ctx* k, uint32_t lq0, uint32_t m, uint32_t off) {
+            return hvs_download_queries(k, lq0, m, out_rows + (size_t)off * HVS_QCOLS);
+        });
     if (!out_rows || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_queries: bad range");
     HVS_HIP(c, hipSetDevice(c->device));
     HVS_HIP(c, hipMemcpyAsync(out_rows, c->d_q + (size_t)q0 * HVS_QCOLS, (size_t)nq * HVS_QCOLS * sizeof(float),
@@ -1003,36 +1557,40 @@ int hvs_download_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float* out_rows)
 int hvs_query_resident(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion)
 {
     if (!c) return HVS_EINVAL;
-    return run_queries(c, q0, nq, sample_proportion);
+    if (!c->kids.empty())
+        return for_each_resident_part(c, q0, nq, [&](hvs_ctx* k, uint32_t lq0, uint32_t m, uint32_t) {
+            return run_queries(k, lq0, m, sample_proportion, NoHook{});
+        });
+    return run_queries(c, q0, nq, sample_proportion, NoHook{});
 }
 
 int hvs_sync(hvs_ctx* c)
 {
     if (!c) return HVS_EINVAL;
-    HVS_HIP(c, hipSetDevice(c->device));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    return HVS_OK;
+    if (!c->kids.empty()) return for_each_leaf(c, [&](uint32_t r) { return leaf_sync(c->kids[r]); });
+    return leaf_sync(c);
 }
 
 int hvs_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_ids, float* out_dists)
 {
     if (!c) return HVS_EINVAL;
-    if (!out_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_results: bad range");
-    HVS_HIP(c, hipSetDevice(c->device));
-    HVS_HIP(c, hipMemcpyAsync(out_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
-                              hipMemcpyDeviceToHost, c->stream));
-    if (out_dists)
-        HVS_HIP(c, hipMemcpyAsync(out_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
-                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HVS_HIP(c, hipStreamSynchronize(c->stream));
-    return HVS_OK;
+    if (!c->kids.empty()) {
+        if (!out_ids) return fail(c, HVS_EINVAL, "hvs_download_results: out_ids is NULL");
+        return for_each_resident_part(c, q0, nq, [&](hvs_ctx* k, uint32_t lq0, uint32_t m, uint32_t off) {
+            return leaf_download_results(k, lq0, m, out_ids + (size_t)off * HVS_KNN, out_dists ? out_dists + (size_t)off * HVS_KNN : nullptr);
+        });
+    }
+    return leaf_download_results(c, q0, nq, out_ids, out_dists);
 }
 
 int hvs_export_results_device(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* d_ids, float* d_dists)
 {
     if (!c) return HVS_EINVAL;
+    if (!c->kids.empty()) return fail(c, HVS_EINVAL, "hvs_export_results_device: single-GPU contexts only (device pointers belong to one GPU)");
     if (!d_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_export_results_device: bad range");
     HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
     HVS_HIP(c, hipMemcpyAsync(d_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
                               hipMemcpyDeviceToDevice, c->stream));
     if (d_dists)
@@ -1045,13 +1603,66 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
               float* out_dists)
 {
     if (!c) return HVS_EINVAL;
-    if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
+    if (c->kids.empty()) return leaf_query(c, q_rows, nq, sample_proportion, out_ids, out_dists);
     if (nq == 0) return HVS_OK;
     if (!q_rows || !out_ids) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
-    int rc = hvs_upload_queries(c, q_rows, nq);
-    if (rc) return rc;
-    if ((rc = run_queries(c, 0, nq, sample_proportion))) return rc;
-    return hvs_download_results(c, 0, nq, out_ids, out_dists);
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t N = (uint32_t)c->kids.size();
+    c->kid_q0.assign(N + 1u, 0u);
+    for (uint32_t r = 0; r < N; ++r) shard_range(nq, r, N, c->kid_q0[r], c->kid_q0[r + 1]);
+    int rc;
+    if (c->gather_mode == HVS_GATHER_DIRECT) {
+        // zero-collective path: every GPU's pipeline reads its slice of the caller's queries and writes its slice of
+        // the caller's result arrays
+        rc = for_each_leaf(c, [&](uint32_t r) -> int {
+            const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
+            if (m == 0u) {
+                c->kids[r]->timing_valid = false;
+                return HVS_OK;
+            }
+            return leaf_query(c->kids[r], q_rows + (size_t)a * HVS_QCOLS, m, sample_proportion, out_ids + (size_t)a * HVS_KNN,
+                              out_dists ? out_dists + (size_t)a * HVS_KNN : nullptr);
+        });
+    } else {
+        // peer gather (A/B partner): every GPU answers its resident slice, the blocks of ids travel GPU -> GPU 0 over
+        // xGMI and leave in one D2H
+        rc = for_each_leaf(c, [&](uint32_t r) -> int {
+            const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
+            hvs_ctx* k = c->kids[r];
+            int r2 = leaf_upload_queries(k, q_rows + (size_t)a * HVS_QCOLS, r == 0u ? m : m);
+            if (r2) return r2;
+            if (r == 0u && (r2 = ensure_results(k, nq))) return r2;  // GPU 0 receives everybody's block
+            if (m == 0u) {
+                k->timing_valid = false;
+                return HVS_OK;
+            }
+            if ((r2 = run_queries(k, 0, m, sample_proportion, NoHook{}))) return r2;
+            return leaf_sync(k);
+        });
+        if (!rc) {
+            hvs_ctx* k0 = c->kids[0];
+            for (uint32_t r = 1; r < N && !rc; ++r) {
+                const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
+                hvs_ctx* k = c->kids[r];
+                if (m == 0u) continue;
+                if (hipMemcpyPeerAsync(k0->d_out_ids + (size_t)a * HVS_KNN, k0->device, k->d_out_ids, k->device,
+                                       (size_t)m * HVS_KNN * sizeof(uint32_t), k0->stream) != hipSuccess ||
+                    (out_dists && hipMemcpyPeerAsync(k0->d_out_dists + (size_t)a * HVS_KNN, k0->device, k->d_out_dists, k->device,
+                                                     (size_t)m * HVS_KNN * sizeof(float), k0->stream) != hipSuccess))
+                    rc = fail(c, HVS_EHIP, "hvs_query: peer copy of a result block failed");
+            }
+            if (!rc) {
+                (void)hipSetDevice(k0->device);
+                if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * HVS_KNN * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
+                    (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost,
+                                                 k0->stream) != hipSuccess) ||
+                    hipStreamSynchronize(k0->stream) != hipSuccess)
+                    rc = fail(c, HVS_EHIP, "hvs_query: download of the gathered results failed");
+            }
+        }
+    }
+    c->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uint32_t* d_ids_all, const float* d_dists_all,
@@ -1059,6 +1670,7 @@ int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uin
                             float* d_out_dists)
 {
     if (!c) return HVS_EINVAL;
+    if (!c->kids.empty()) return fail(c, HVS_EINVAL, "hvs_merge_shards_device: single-GPU contexts only");
     if (!d_ids_all || !d_dists_all || !shard_row0 || !d_pad_dists || !d_out_ids || nshards == 0u || nshards > 16u ||
         n_total < HVS_KNN)
         return fail(c, HVS_EINVAL, "hvs_merge_shards_device: bad argument (1..16 shards, n_total >= 100, non-NULL buffers)");
@@ -1078,25 +1690,31 @@ int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uin
 int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
 {
     if (!c || !out) return HVS_EINVAL;
-    if (!c->timing_valid) return fail(c, HVS_ESTATE, "no query has run yet");
-    HVS_HIP(c, hipSetDevice(c->device));
-    HVS_HIP(c, hipEventSynchronize(c->ev_q1));
-    float ms = 0.f;
-    HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
-    c->timing.query_ms = ms;
-    double k = 0.0;
-    for (int i = 0; i < c->n_launch_events; ++i) {
-        HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_k0[i], c->ev_k1[i]));
-        k += ms;
+    if (c->kids.empty()) return leaf_last_timing(c, out);
+    // whole-job view: device time = the slowest GPU's, work counters summed over the GPUs that took part
+    hvs_timing agg{};
+    bool any = false;
+    for (hvs_ctx* k : c->kids) {
+        if (!k->timing_valid) continue;
+        hvs_timing t{};
+        const int rc = leaf_last_timing(k, &t);
+        if (rc) return fail(c, rc, k->err);
+        agg.query_ms = std::max(agg.query_ms, t.query_ms);
+        agg.main_kernel_ms += t.main_kernel_ms;
+        agg.main_kernel_launches += t.main_kernel_launches;
+        agg.nq += t.nq;
+        agg.pairs += t.pairs;
+        agg.scanned_pairs += t.scanned_pairs;
+        agg.rescored_pairs += t.rescored_pairs;
+        agg.fallback_queries += t.fallback_queries;
+        agg.load_ms = std::max(agg.load_ms, t.load_ms);
+        agg.engine = t.engine;
+        agg.n_gpus += 1;
+        any = true;
     }
-    c->timing.main_kernel_ms = k;
-    c->timing.main_kernel_launches = (uint32_t)c->n_launch_events;
-    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HVS_HIP(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-    c->timing.pairs = h[0];
-    c->timing.scanned_pairs = h[1];
-    c->timing.rescored_pairs = h[2];
-    *out = c->timing;
+    if (!any) return fail(c, HVS_ESTATE, "no query has run yet");
+    agg.host_ms = c->host_ms;
+    *out = agg;
     return HVS_OK;
 }
 

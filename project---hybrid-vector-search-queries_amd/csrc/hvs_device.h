@@ -17,8 +17,9 @@
 // ---------------------------------------------------------------------------------------------
 // Query parameters: reference include/optimized_parallel.hpp:93-96
 //   query_type = uint32(q[0]); v = int32(q[1]) (truncation); l = q[2]; r = q[3]
-// `nodes[j][0] == v` compares the row's float with float(v).  Types outside 0..3 (and values
-// whose conversion is undefined behaviour in the reference) match no row: type 4.
+// `nodes[j][0] == v` compares the row's float with float(v).  uint32(t) truncates toward zero, so t in (-1, 0) is
+// type 0, and int32(-2^31) is INT_MIN (both conversions are defined).  Types outside 0..3 (and values whose
+// conversion is undefined behaviour in the reference) match no row: type 4.
 // ---------------------------------------------------------------------------------------------
 struct HvsQParams {
     uint32_t type;
@@ -29,9 +30,9 @@ __device__ __forceinline__ HvsQParams hvs_parse_query(const float* __restrict__ 
 {
     HvsQParams p;
     const float t = q[0];
-    p.type = (t >= 0.0f && t < 4.0f) ? (uint32_t)t : 4u;
+    p.type = (t > -1.0f && t < 4.0f) ? (uint32_t)(int32_t)t : 4u;
     const float v = q[1];
-    if (v > -2147483648.0f && v < 2147483648.0f) {
+    if (v >= -2147483648.0f && v < 2147483648.0f) {
         p.vf = (float)(int32_t)v;
     } else {
         p.vf = 0.0f;
@@ -144,11 +145,15 @@ __device__ __forceinline__ float hvs_scalar_order_dist(const DV& d, const QV& q)
 // ---------------------------------------------------------------------------------------------
 // Candidate keys: (distance bits << 32) | row id.  Distances are sums of squares (>= +0), so
 // their IEEE bit patterns order like unsigned integers and ascending u64 order is exactly the
-// canonical result order (dist asc, id asc) of SURVEY.md 8c.
+// canonical result order (dist asc, id asc) of SURVEY.md 8c.  Non-finite distances (inf/NaN components or
+// overflow) get a defined place: +inf after every finite value, NaN (one canonical bit pattern) after +inf.  The
+// reference admits any row while its list is not full (optimized_impl.h:301-304: add_new_vec = not_full || better)
+// and then sorts with std::sort, whose result for NaN keys is unspecified -- this order is the build's own choice there.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t hvs_make_key(float dist, uint32_t id)
 {
-    return ((uint64_t)__float_as_uint(dist) << 32) | (uint64_t)id;
+    const uint32_t bits = (dist != dist) ? 0x7FC00000u : __float_as_uint(dist);
+    return ((uint64_t)bits << 32) | (uint64_t)id;
 }
 __device__ __forceinline__ float hvs_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t hvs_key_id(uint64_t key) { return (uint32_t)key; }

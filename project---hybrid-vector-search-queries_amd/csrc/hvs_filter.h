@@ -686,9 +686,6 @@ __device__ __forceinline__ void hvs_query_range(const HvsQParams& p, const uint6
 // sort key of a query inside a batch: rank:3 | bin of the range start:12 | range end:32.
 // Queries that share a wave (128 consecutive slots) then have nearly the same position range, so
 // the union range the wave has to stream is close to each query's own range.
-struct HvsBins {
-    uint32_t nbins[5];  // start-position bins per predicate class rank
-};
 
 // population of each predicate class in the batch (sizes the start-position bins)
 __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint32_t* __restrict__ counts)
@@ -704,9 +701,11 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
     }
 }
 
+// `counts`: the batch's class populations (hvs_k_count_classes) -- read on the device, so that forming a batch needs
+// no host round trip: ~4096 queries of a class per start-position bin
 __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
                                   const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
-                                  HvsBins bins, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+                                  const uint32_t* __restrict__ counts, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
@@ -714,7 +713,9 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     const uint32_t rk = hvs_type_rank(p.type);
     uint32_t a, b;
     hvs_query_range(p, keys_ct, keys_t, n, a, b);
-    const uint32_t abin = (uint32_t)(((uint64_t)a * bins.nbins[rk]) / ((uint64_t)n + 1ull));
+    uint32_t nbins = counts[rk] / 4096u;
+    nbins = nbins < 1u ? 1u : (nbins > 4096u ? 4096u : nbins);
+    const uint32_t abin = (uint32_t)(((uint64_t)a * nbins) / ((uint64_t)n + 1ull));
     keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
     idx[i] = q0 + i;
 }
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restr
         q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
     }
     uint64_t* __restrict__ mylist = cand + ((size_t)chunk * B.nslots + slot) * 256u;
-    float tau = __builtin_inff();
+    float tau = __builtin_nanf("");  // admits every passing row until the first cut (see hvs_k_scan_exact)
     uint32_t cnt = 0, nscan = 0;
     for (uint32_t pos = p0; pos < p1; ++pos) {
         const bool pass = pos >= ra && pos < rb;
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restr
             HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(row)};
             dist = hvs_exact_dist_pk(dv, q2);
         }
-        if (pass && dist <= tau) {  // ids are not monotone along a position range: keep ties, the keys sort them out
+        if (pass && !(dist > tau)) {  // ids are not monotone along a position range: keep ties, the keys sort them out
             mylist[cnt] = hvs_make_key(dist, id);
             ++cnt;
         }
@@ -2138,7 +2139,8 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     }
 }
 
-// queries whose candidate lists overflowed -> compact list for the exact engine
+// queries whose candidate lists overflowed -> appended to the call's list for the exact engine (`count` runs over all
+// batches of a call)
 __global__ void hvs_k_collect_overflow(HvsBatch B, uint32_t* __restrict__ list, uint32_t* __restrict__ count)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
     if (r1 > sn || r1 < r0) r1 = sn;
 
     uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
-    float tau = __builtin_inff();
+    // tau = NaN until the list has been cut back once: `!(dist >= tau)` then admits EVERY passing row, +inf and NaN
+    // distances included, as the reference does while its list is not full (optimized_impl.h:301-304)
+    float tau = __builtin_nanf("");
     uint32_t cnt = 0;
     uint32_t npass = 0, nscan = 0;  // per-wave statistics (uniform)
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
             dist = hvs_exact_dist_pk(dv, q2);
         }
 
-        if (pass && dist < tau) {
+        if (pass && !(dist >= tau)) {
             mylist[cnt] = hvs_make_key(dist, j);
             ++cnt;
         }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
     };
 
     uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
-    float tau = __builtin_inff();
+    float tau = __builtin_nanf("");  // (see hvs_k_scan_exact)
     uint32_t cnt = 0;
     uint32_t npass = 0, nscan = 0;
 
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
                     HvsLdsRow2 dv{rowp};
                     dist = hvs_exact_dist_pk(dv, q2);
                 }
-                if (pass && dist < tau) {
+                if (pass && !(dist >= tau)) {
                     mylist[cnt] = hvs_make_key(dist, j0 + r);
                     ++cnt;
                 }

@@ -7,6 +7,7 @@
 // (test.cpp:82-88: data already in host memory -> ids back in host memory), prints
 // "Vector Search took <ms> ms" on stderr (test.cpp:91-92), writes output.bin (io.h:23-36) and
 // <output>.dist with the scalar-order distances of the chosen rows (test.cpp:97-110, io.h:38-78).
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -64,11 +65,19 @@ int main(int argc, char** argv)
         return 2;
     }
 
+    // like the reference, which sizes its own worker pool from the machine (optimized_parallel.hpp:73-78), the driver
+    // uses every GPU of the node: one per 32768 queries, at most all; HVS_GPUS=n overrides
+    int gpus = hvs_device_count();
+    if (gpus < 1) gpus = 1;
+    int use = (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)gpus, nq / 32768u));
+    if (const char* e = std::getenv("HVS_GPUS"))
+        if (std::atoi(e) >= 1) use = std::min(std::atoi(e), gpus);
     hvs_ctx* ctx = nullptr;
-    if (hvs_create(&ctx, -1) != HVS_OK) {
+    if (hvs_create_multi(&ctx, use) != HVS_OK) {
         std::cerr << hvs_last_global_error() << "\n";
         return 3;
     }
+    (void)hvs_reserve(ctx, nq);
     std::vector<uint32_t> ids((size_t)nq * 100);
     std::cout << "# data points:  " << n << "\n# data point dim:  102\n# queries:      " << nq << "\n";
     const auto t0 = std::chrono::steady_clock::now();
@@ -83,7 +92,8 @@ int main(int argc, char** argv)
     hvs_timing tm{};
     if (nq) hvs_last_timing(ctx, &tm);
     std::cerr << "Vector Search took " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms"
-              << " (device query " << tm.query_ms << " ms, data upload+index " << tm.load_ms << " ms)" << std::endl;
+              << " (" << hvs_num_gpus(ctx) << " GPU(s): query host->host " << tm.host_ms << " ms, of it on the device " << tm.query_ms
+              << " ms; data upload+index " << tm.load_ms << " ms)" << std::endl;
     hvs_destroy(ctx);
 
     FILE* f = std::fopen(knn_save_path.c_str(), "wb");

@@ -29,7 +29,8 @@ class HvsError(RuntimeError):
 class Timing(C.Structure):
     _fields_ = [("query_ms", C.c_double), ("main_kernel_ms", C.c_double), ("main_kernel_launches", C.c_uint32),
                 ("nq", C.c_uint32), ("pairs", C.c_uint64), ("scanned_pairs", C.c_uint64), ("load_ms", C.c_double),
-                ("engine", C.c_uint32), ("fallback_queries", C.c_uint32), ("rescored_pairs", C.c_uint64)]
+                ("engine", C.c_uint32), ("fallback_queries", C.c_uint32), ("rescored_pairs", C.c_uint64),
+                ("n_gpus", C.c_uint32), ("reserved", C.c_uint32), ("host_ms", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -41,12 +42,14 @@ def library_path():
 
 def sources():
     return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h", ".cpp"))] + [
-        _HDR, os.path.join(_REPO, "include", "hvs_gen.h")]
+        _HDR, os.path.join(_REPO, "include", "hvs_gen.h"), os.path.join(_REPO, "include", "hvs_vec_query.hpp"),
+        os.path.join(_REPO, "tests", "seam_main.cpp")]
 
 
 def build_library(force=False, verbose=False):
     """Compile csrc/hvs.hip for gfx950 into csrc/libhvs.so (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in sources()):
+    if (not force and os.path.exists(_LIB) and os.path.exists(cli_path()) and os.path.exists(seam_path())
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in sources())):
         return _LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "hvs.hip"), "-o", _LIB]
@@ -54,6 +57,7 @@ def build_library(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=_CSRC)
     build_cli(verbose)
+    build_seam(verbose)
     return _LIB
 
 
@@ -73,6 +77,20 @@ def build_cli(verbose=False):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=_CSRC)
     return cli_path()
+
+
+def seam_path():
+    """tests/seam_main.cpp: the reference's src/test.cpp with include/hvs_vec_query.hpp as its engine header."""
+    return os.path.join(_REPO, "tests", "seam_main.out")
+
+
+def build_seam(verbose=False):
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(_REPO, "include"), os.path.join(_REPO, "tests", "seam_main.cpp"),
+           "-L" + _CSRC, "-lhvs", "-Wl,-rpath," + _CSRC, "-o", seam_path()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return seam_path()
 
 
 def compare_path():
@@ -103,6 +121,12 @@ def library():
     vp = C.c_void_p
     sig = {
         "hvs_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "hvs_create_multi": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "hvs_create_on_devices": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
+        "hvs_num_gpus": (C.c_int, [vp]),
+        "hvs_device_count": (C.c_int, []),
+        "hvs_set_gather": (C.c_int, [vp, C.c_int]),
+        "hvs_reserve": (C.c_int, [vp, C.c_uint32]),
         "hvs_destroy": (None, [vp]),
         "hvs_last_error": (C.c_char_p, [vp]),
         "hvs_last_global_error": (C.c_char_p, []),
@@ -141,15 +165,35 @@ def _up(a):
 
 
 class Engine:
-    """One hvs_ctx: one GPU, one stream, D resident in HBM."""
+    """One hvs_ctx.  Engine(device): one GPU.  Engine(n_gpus=N) (0 = all visible) or Engine(devices=[...]): the
+    multi-GPU context of hvs_create_multi / hvs_create_on_devices -- D replicated, the queries of a call partitioned,
+    every GPU writing its slice of the result (a device index may repeat: virtual ranks on one GPU)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, n_gpus=None, devices=None):
         self._lib = library()
         h = C.c_void_p()
-        rc = self._lib.hvs_create(C.byref(h), device)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._lib.hvs_create_on_devices(C.byref(h), arr, len(devices))
+        elif n_gpus is not None:
+            rc = self._lib.hvs_create_multi(C.byref(h), int(n_gpus))
+        else:
+            rc = self._lib.hvs_create(C.byref(h), device)
         if rc != 0:
             raise HvsError(rc, self._lib.hvs_last_global_error().decode())
         self._h = h
+
+    @property
+    def num_gpus(self):
+        return int(self._lib.hvs_num_gpus(self._h))
+
+    def set_gather(self, mode):
+        """0 = every GPU copies its block into its slice of the caller's array, 1 = peer gather to GPU 0 first."""
+        self._ck(self._lib.hvs_set_gather(self._h, int(mode)))
+
+    def reserve(self, nq):
+        """Allocate query/result buffers and the batch workspace for calls of up to nq queries now."""
+        self._ck(self._lib.hvs_reserve(self._h, int(nq)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -199,15 +243,21 @@ class Engine:
         return int(self._lib.hvs_num_rows(self._h))
 
     # --- the vec_query seam
-    def query(self, q_rows, sample_proportion=1.0, want_dists=True):
+    def query(self, q_rows, sample_proportion=1.0, want_dists=True, out_ids=None, out_dists=None):
+        """hvs_query: host rows in, host ids (and distances) out.  `out_ids` / `out_dists`: caller-provided arrays
+        (e.g. views of pinned memory) to be filled instead of fresh ones."""
         q = np.ascontiguousarray(q_rows, np.float32)
         if q.ndim != 2 or q.shape[1] != QCOLS:
             raise HvsError(-1, "query rows must be nq x 104 float32")
         nq = q.shape[0]
-        ids = np.empty((nq, K), np.uint32)
-        d = np.empty((nq, K), np.float32) if want_dists else None
-        self._ck(self._lib.hvs_query(self._h, _fp(q), nq, sample_proportion, _up(ids), _fp(d) if want_dists else None))
-        return (ids, d) if want_dists else ids
+        ids = out_ids if out_ids is not None else np.empty((nq, K), np.uint32)
+        d = out_dists if out_dists is not None else (np.empty((nq, K), np.float32) if want_dists else None)
+        if ids.shape != (nq, K) or ids.dtype != np.uint32 or not ids.flags.c_contiguous:
+            raise HvsError(-1, "out_ids must be a C-contiguous nq x 100 uint32 array")
+        if d is not None and (d.shape != (nq, K) or d.dtype != np.float32 or not d.flags.c_contiguous):
+            raise HvsError(-1, "out_dists must be a C-contiguous nq x 100 float32 array")
+        self._ck(self._lib.hvs_query(self._h, _fp(q), nq, sample_proportion, _up(ids), _fp(d) if d is not None else None))
+        return (ids, d) if d is not None else ids
 
     # --- resident variant
     def upload_queries(self, q_rows):

@@ -16,17 +16,23 @@ from .engine import Engine, HvsError
 _engine_cache = {}
 
 
-def vec_query(nodes, queries, sample_proportion, knn_results, device=-1):
+def vec_query(nodes, queries, sample_proportion, knn_results, n_gpus=None):
     """Drop-in for the reference's vec_query.  `nodes`: n x 102, `queries`: nq x 104 (sequences of
     rows or arrays).  Like the reference it reports nothing: preconditions are the caller's
     (n >= 100, full rows); unlike it, a violated precondition raises instead of reading out of
-    bounds."""
+    bounds.  Like the reference, which sizes its own thread pool (optimized_parallel.hpp:73-78), the call
+    spreads over the node's GPUs: one per 32768 queries, at most all (`n_gpus` overrides)."""
     nodes = np.ascontiguousarray(nodes, np.float32)
     queries = np.ascontiguousarray(queries, np.float32)
     print(f"# data points:  {nodes.shape[0]}")
     print(f"# data point dim:  {nodes.shape[1] if nodes.ndim == 2 else 0}")
     print(f"# queries:      {queries.shape[0]}")
-    with Engine(device) as eng:
+    if n_gpus is None:
+        from .engine import library
+        have = max(1, int(library().hvs_device_count()))
+        n_gpus = max(1, min(have, queries.shape[0] // 32768))
+    with Engine(n_gpus=n_gpus) as eng:
+        eng.reserve(queries.shape[0])
         eng.load_data(nodes)
         ids = eng.query(queries, sample_proportion, want_dists=False) if queries.shape[0] else np.empty((0, 100), np.uint32)
     for row in ids:

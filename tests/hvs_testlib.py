@@ -243,8 +243,8 @@ def sha256_of(*arrays):
 def _passes(nodes, q):
     """Predicate of one query over all rows (reference optimized_parallel.hpp:93-96,105-138)."""
     t = q[0]
-    typ = int(t) if 0.0 <= t < 4.0 else 4
-    vf = np.float32(int(q[1])) if abs(float(q[1])) < 2147483648.0 else None
+    typ = int(t) if -1.0 < t < 4.0 else 4                        # uint32(t) truncates toward zero: (-1, 0) -> type 0
+    vf = np.float32(int(q[1])) if -2147483648.0 <= float(q[1]) < 2147483648.0 else None
     c, tt = nodes[:, 0], nodes[:, 1]
     if typ == 0:
         return np.ones(nodes.shape[0], bool)

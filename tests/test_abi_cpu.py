@@ -62,6 +62,20 @@ def test_fails_loudly_without_a_gpu():
         PKG.vec_query(T.gen_data(128), T.gen_queries(2), 1.0, [])
 
 
+@pytest.mark.skipif(_has_gpu(), reason="needs a GPU-less host")
+def test_seam_translation_unit_builds_and_fails_cleanly_without_a_gpu(tmp_path):
+    """tests/seam_main.cpp (src/test.cpp's body + include/hvs_vec_query.hpp, the reference's exact vec_query
+    signature) compiles against the C ABI; without a GPU the call ends in the shim's exception, not in a CPU path."""
+    import subprocess
+    PKG.build_seam()
+    T.write_bin(str(tmp_path / "d.bin"), T.gen_data(200))
+    T.write_bin(str(tmp_path / "q.bin"), T.gen_queries(3))
+    r = subprocess.run([PKG.seam_path(), str(tmp_path / "d.bin"), str(tmp_path / "q.bin"), str(tmp_path / "o.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr, r.stderr
+    assert "# data points:  200" in r.stdout      # the size lines of optimized_parallel.hpp:69-71
+
+
 def test_io_mirror_roundtrip(tmp_path):
     nodes = T.gen_data(300)
     p = tmp_path / "d.bin"
