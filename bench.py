@@ -174,7 +174,8 @@ def main():
                        "sharding": "Q partitioned across ranks, D replicated, RCCL gather of the ids to rank 0"},
             "roofline": {"bound": "mfma" if engine_id in (2, 3) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": {2: "hvs_k_filter_mfma<bf16>", 3: "hvs_k_filter_mfma<int8>"}.get(engine_id, "hvs_k_scan_exact"),
+                         "kernel": {2: "hvs_k_filter_mfma<bf16>",
+                                    3: "hvs_k_filter_mfma<int8>" if os.environ.get("HVS_I8_SHAPE") == "32" else "hvs_k_filter_i8x16"}.get(engine_id, "hvs_k_scan_exact"),
                          "peak_is": {2: "dense BF16 MFMA", 3: "dense INT8 MFMA (integer ops)"}.get(engine_id, "FP32 vector"),
                          "kernel_ms_avg": kern_ms / max(kern_launches, 1), "launches": kern_launches,
                          "pairs_per_launch": pairs / max(kern_launches, 1),

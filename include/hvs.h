@@ -16,8 +16,8 @@
  * Conventions: plain pointers and sizes, no exceptions, int status (0 = ok, negative =
  * HVS_E*), one hvs_ctx is used from one thread at a time (the reference has a single
  * caller, src/test.cpp:85), all work of a context runs on the context's own HIP stream
- * on one GPU.  k = 100 and dim = 100 are compile-time constants like the reference's
- * KNN_LIMIT / VEC_DIM (include/optimized_impl.h:26-28).
+ * on one GPU.  dim = 100 is a compile-time constant like the reference's VEC_DIM (include/optimized_impl.h:28);
+ * k defaults to the reference's KNN_LIMIT = 100 (optimized_impl.h:26) and can be changed per context (hvs_set_k).
  */
 #ifndef HVS_H
 #define HVS_H
@@ -100,6 +100,12 @@ int hvs_set_engine(hvs_ctx *ctx, int engine);
 #define HVS_ORDER_SIMD 0
 #define HVS_ORDER_SCALAR 1
 int hvs_set_distance_order(hvs_ctx *ctx, int order);
+/* Neighbours per query: the reference's compile-time KNN_LIMIT (include/optimized_impl.h:26, static_assert >= 8),
+ * a run-time property here.  8 <= k <= 256, default 100; every "100" in the layouts below reads "k" after the call
+ * (out_ids / out_dists rows hold k entries, the data set needs n >= k rows, padding appends rows n-1, n-2, ... up to
+ * k).  Results of earlier queries are dropped. */
+int hvs_set_k(hvs_ctx *ctx, uint32_t k);
+uint32_t hvs_get_k(const hvs_ctx *ctx);
 /* Padding (default on) appends rows n-1, n-2, ... when fewer than 100 rows match
  * (optimized_parallel.hpp:149-157).  A context that holds only a SHARD of D (D-sharded multi-GPU mode,
  * sharding.py) turns it off: unmatched slots then carry id 0xFFFFFFFF / distance +inf and the merge of

@@ -28,7 +28,18 @@
 
 #define DCOLS 102
 #define QCOLS 104
-#define KNN 100
+/* k: the reference's compile-time KNN_LIMIT (optimized_impl.h:26).  100 unless a test changes it with
+ * hvs_oracle_set_k (8..256; process-wide, set before the calls that use it -- the checker is single-tenant). */
+#define KNN_MAX 256
+static int g_knn = 100;
+#define KNN g_knn
+int hvs_oracle_set_k(int k)
+{
+    if (k < 8 || k > KNN_MAX) return -1;
+    g_knn = k;
+    return 0;
+}
+int hvs_oracle_get_k(void) { return g_knn; }
 
 /* ------------------------------------------------------------------------- *
  * Distances
@@ -273,7 +284,7 @@ static void one_query_canonical(const float *nodes, uint32_t n, uint32_t sn, con
 int hvs_oracle_vec_query(const float *nodes, uint32_t n, const float *queries, uint32_t nq,
                          float sample_proportion, uint32_t *out_ids, float *out_dists, int threads)
 {
-    if (n < KNN) return -1;
+    if (n < (uint32_t)KNN) return -1;
     const uint32_t sn = hvs_oracle_sn(sample_proportion, n);
     (void)threads;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
@@ -292,14 +303,15 @@ int hvs_oracle_vec_query(const float *nodes, uint32_t n, const float *queries, u
  * ------------------------------------------------------------------------- */
 
 typedef struct {
-    float dist[KNN];
-    uint32_t idx[KNN];
+    float dist[KNN_MAX];
+    uint32_t idx[KNN_MAX];
     uint32_t fill, worst;
 } knn_t;
 
 /* optimized_impl.h:205-255 (FIND_WORST_SIMD=1): per AVX lane strict '>' keeps the
- * earliest slot; overlapping last step covers slots 92..99; across lanes the largest
- * slot index among the maxima wins (_mm256_max_epu32). */
+ * earliest slot; full 8-wide steps over slots 8 .. K - K%8, then one overlapping step on the last
+ * 8 slots (92..99 at K = 100); across lanes the largest slot index among the maxima wins
+ * (_mm256_max_epu32). */
 static uint32_t knn_find_worst(const knn_t *k)
 {
     float lane_d[8];
@@ -308,16 +320,16 @@ static uint32_t knn_find_worst(const knn_t *k)
         lane_d[j] = k->dist[j];
         lane_i[j] = (uint32_t)j;
     }
-    for (int i = 8; i < 96; i += 8)
+    for (int i = 8; i < KNN - (KNN % 8); i += 8) /* optimized_impl.h:212 */
         for (int j = 0; j < 8; ++j)
             if (k->dist[i + j] > lane_d[j]) {
                 lane_d[j] = k->dist[i + j];
                 lane_i[j] = (uint32_t)(i + j);
             }
-    for (int j = 0; j < 8; ++j)
-        if (k->dist[92 + j] > lane_d[j]) {
-            lane_d[j] = k->dist[92 + j];
-            lane_i[j] = (uint32_t)(92 + j);
+    for (int j = 0; j < 8; ++j) /* optimized_impl.h:224-233: slots K-8 .. K-1 */
+        if (k->dist[KNN - 8 + j] > lane_d[j]) {
+            lane_d[j] = k->dist[KNN - 8 + j];
+            lane_i[j] = (uint32_t)(KNN - 8 + j);
         }
     float m = lane_d[0];
     for (int j = 1; j < 8; ++j)
@@ -331,7 +343,7 @@ static uint32_t knn_find_worst(const knn_t *k)
 /* optimized_impl.h:284-311 (branchless variant); also the body of merge, :337-385 */
 static inline void knn_offer(knn_t *k, float d, uint32_t id)
 {
-    const int not_full = k->fill < KNN;
+    const int not_full = k->fill < (uint32_t)KNN;
     const float worst_dist = k->dist[k->worst];
     const int better = d < worst_dist;
     const int add = not_full || better;
@@ -356,7 +368,7 @@ static void knn_finish(knn_t *k, const float *nodes, uint32_t n, const float *qv
                        float *out_dists)
 {
     uint32_t s = 1;
-    while (k->fill < KNN) { /* optimized_parallel.hpp:149-157 */
+    while (k->fill < (uint32_t)KNN) { /* optimized_parallel.hpp:149-157 */
         const uint32_t id = n - s;
         knn_offer(k, hvs_oracle_dist_simd_order(nodes + (size_t)id * DCOLS + 2, qvec), id);
         ++s;
@@ -389,7 +401,7 @@ int hvs_oracle_vec_query_knn(const float *nodes, uint32_t n, const float *querie
                              float sample_proportion, uint32_t *out_ids, float *out_dists, int part_threads,
                              int hw_threads, int run_parallel)
 {
-    if (n < KNN) return -1;
+    if (n < (uint32_t)KNN) return -1;
     const uint32_t sn = hvs_oracle_sn(sample_proportion, n);
     uint32_t T = (uint32_t)part_threads;
     if (part_threads <= 0) {
@@ -476,7 +488,7 @@ static int bcand_cmp(const void *a, const void *b)
 int hvs_oracle_vec_query_baseline(const float *nodes, uint32_t n, const float *queries, uint32_t nq,
                                   float sample_proportion, uint32_t *out_ids, float *out_dists)
 {
-    if (n < KNN) return -1;
+    if (n < (uint32_t)KNN) return -1;
     const uint32_t sn = hvs_oracle_sn(sample_proportion, n);
     uint32_t *ids = (uint32_t *)malloc(((size_t)sn + KNN) * sizeof(uint32_t));
     bcand *bc = (bcand *)malloc(((size_t)sn + KNN) * sizeof(bcand));
@@ -492,7 +504,7 @@ int hvs_oracle_vec_query_baseline(const float *nodes, uint32_t n, const float *q
         for (uint32_t j = 0; j < sn; ++j)
             if (row_passes(&p, nodes + (size_t)j * DCOLS)) ids[m++] = j;
         uint32_t s = 1;
-        while (m < KNN) ids[m++] = n - s++;
+        while (m < (size_t)KNN) ids[m++] = n - s++;
         for (size_t c = 0; c < m; ++c) {
             bc[c].d = hvs_oracle_dist_scalar_order(nodes + (size_t)ids[c] * DCOLS + 2, q + 4);
             bc[c].pos = (uint32_t)c;

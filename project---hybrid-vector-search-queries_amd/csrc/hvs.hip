@@ -13,6 +13,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -32,6 +33,8 @@ struct hvs_ctx {
     hipStream_t stream = nullptr;
     int engine = HVS_ENGINE_AUTO;
     bool scalar_order = false;  // baseline engine's summation order (exact engine only)
+    uint32_t k = HVS_KNN;       // neighbours per query (hvs_set_k; the reference's KNN_LIMIT, optimized_impl.h:26)
+    int cap = 256;              // candidate-list capacity the kernels run with: 256 (k <= 128) or 512 (k <= 256)
     bool padding = true;        // pad answers with the last rows of D (off: partial answers of a data shard)
     std::string err;
 
@@ -106,6 +109,7 @@ struct hvs_ctx {
     hipEvent_t ev_in[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_out[kRing] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_batch = nullptr, ev_stage = nullptr;
     uint32_t reserve_nq = 0;  // hvs_reserve: queries per call the caller announced
+    uint32_t stage_k = 0;     // k the pinned result slots were sized for
 
     // multi-GPU root (hvs_create_multi): owns one leaf context per GPU; D is replicated, the queries of a call are cut
     // into one contiguous range per leaf (optimized_parallel.hpp:91: iterations are independent) and every leaf
@@ -183,6 +187,16 @@ void kernel_timer_end(hvs_ctx* c, int ev)
     if (hipEventRecord(c->ev_k[2 * ev + 1], c->stream) == hipSuccess) c->n_launch_events = ev + 1;
 }
 
+// the select / merge / scan kernels exist for two list capacities; `f` gets the capacity as a compile-time constant
+template <typename F>
+void with_cap(int cap, F f)
+{
+    if (cap == 512)
+        f(std::integral_constant<int, 512>{});
+    else
+        f(std::integral_constant<int, 256>{});
+}
+
 // optimized_parallel.hpp:67: const uint32_t sn = uint32_t(sample_proportion * n);  (float product)
 uint32_t sample_rows(float sample_proportion, uint32_t n)
 {
@@ -197,8 +211,8 @@ int ensure_results(hvs_ctx* c, uint32_t nq)
 {
     if (nq <= c->res_cap) return HVS_OK;
     int rc;
-    if ((rc = dev_alloc(c, &c->d_out_ids, (size_t)nq * HVS_KNN))) return rc;
-    if ((rc = dev_alloc(c, &c->d_out_dists, (size_t)nq * HVS_KNN))) return rc;
+    if ((rc = dev_alloc(c, &c->d_out_ids, (size_t)nq * c->k))) return rc;
+    if ((rc = dev_alloc(c, &c->d_out_dists, (size_t)nq * c->k))) return rc;
     if ((rc = dev_alloc(c, &c->d_ovf_list, (size_t)nq))) return rc;
     c->res_cap = nq;
     return HVS_OK;
@@ -253,7 +267,7 @@ int ensure_batch_workspace(hvs_ctx* c, uint32_t nqb, const Plan& p)
     }
     const size_t lists = (size_t)p.nq_pad * p.nchunks;
     if (lists > c->cand_lists) {
-        if ((rc = dev_alloc(c, &c->d_cand, lists * HVS_CAND_CAP))) return rc;
+        if ((rc = dev_alloc(c, &c->d_cand, lists * (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &c->d_cand_cnt, lists))) return rc;
         c->cand_lists = lists;
     }
@@ -285,29 +299,35 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
     if (sn > 0) {
         unsigned long long* stat = count_stats ? c->d_counters : c->d_counters + 4;
         const dim3 grid(p.nq_pad / 256u, p.nchunks);
-        if (kScanRowsThroughLds) {
-            if (c->scalar_order)
-                hipLaunchKernelGGL(hvs_k_scan_exact_lds<true>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
-                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
-            else
-                hipLaunchKernelGGL(hvs_k_scan_exact_lds<false>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
-                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
-        } else {
-            if (c->scalar_order)
-                hipLaunchKernelGGL(hvs_k_scan_exact<true>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
-                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
-            else
-                hipLaunchKernelGGL(hvs_k_scan_exact<false>, grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
-                                   p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat);
-        }
+        with_cap(c->cap, [&](auto CAPT) {
+            constexpr int CAP = decltype(CAPT)::value;
+            if (kScanRowsThroughLds) {
+                if (c->scalar_order)
+                    hipLaunchKernelGGL((hvs_k_scan_exact_lds<true, CAP>), grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                       p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);
+                else
+                    hipLaunchKernelGGL((hvs_k_scan_exact_lds<false, CAP>), grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                       p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);
+            } else {
+                if (c->scalar_order)
+                    hipLaunchKernelGGL((hvs_k_scan_exact<true, CAP>), grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                       p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);
+                else
+                    hipLaunchKernelGGL((hvs_k_scan_exact<false, CAP>), grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
+                                       p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);
+            }
+        });
     }
     kernel_timer_end(c, ev);
-    if (c->scalar_order)
-        hipLaunchKernelGGL(hvs_k_select<true>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
-    else
-        hipLaunchKernelGGL(hvs_k_select<false>, dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
+    with_cap(c->cap, [&](auto CAPT) {
+        constexpr int CAP = decltype(CAPT)::value;
+        if (c->scalar_order)
+            hipLaunchKernelGGL((hvs_k_select<true, CAP>), dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                               qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, c->k);
+        else
+            hipLaunchKernelGGL((hvs_k_select<false, CAP>), dim3((nqb + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                               qorder, nqb, p.nq_pad, p.nchunks, c->d_cand, c->d_cand_cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, c->k);
+    });
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -551,7 +571,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
         HVS_A(normq, slots);
         HVS_A(eq, slots);
         HVS_A(nqb, slots);
-        HVS_A(top, (size_t)slots * HVS_TOPCAP);
+        HVS_A(top, (size_t)slots * 256u);  // stride 128 (k <= 128) or 256
         HVS_A(topcnt, slots);
         HVS_A(tau, slots);
         HVS_A(cand, (size_t)slots * HVS_FCAP);
@@ -566,6 +586,8 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
     }
     B.nslots = slots;
     B.ngroups = slots / HVS_GROUP;
+    B.knn = c->k;
+    B.topcap = c->k <= 128u ? 128u : 256u;
     // sort workspace shared with the exact engine
     Plan p{};
     p.nq_pad = 256;
@@ -637,29 +659,35 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     nchunks = std::min(nchunks, std::max(1u, (1u << 20) / B.nslots));  // candidate lists: at most 2 GB
     const size_t lists = (size_t)B.nslots * nchunks;
     if (lists > c->cand_lists) {
-        if ((rc = dev_alloc(c, &c->d_cand, lists * HVS_CAND_CAP))) return rc;
+        if ((rc = dev_alloc(c, &c->d_cand, lists * (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &c->d_cand_cnt, lists))) return rc;
         c->cand_lists = lists;
     }
     HVS_HIP(c, hipMemsetAsync(c->d_cand_cnt, 0, lists * sizeof(uint32_t), c->stream));
     const int ev = kernel_timer_begin(c);
     const dim3 grid((slot_end + 255u) / 256u, nchunks);
-    if (c->scalar_order)
-        hipLaunchKernelGGL(hvs_k_scan_ranges<true>, grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
-                           c->d_perm_t, nchunks, slot_begin, slot_end, c->d_cand, c->d_cand_cnt, c->d_counters);
-    else
-        hipLaunchKernelGGL(hvs_k_scan_ranges<false>, grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
-                           c->d_perm_t, nchunks, slot_begin, slot_end, c->d_cand, c->d_cand_cnt, c->d_counters);
+    with_cap(c->cap, [&](auto CAPT) {
+        constexpr int CAP = decltype(CAPT)::value;
+        if (c->scalar_order)
+            hipLaunchKernelGGL((hvs_k_scan_ranges<true, CAP>), grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
+                               c->d_perm_t, nchunks, slot_begin, slot_end, c->d_cand, c->d_cand_cnt, c->d_counters);
+        else
+            hipLaunchKernelGGL((hvs_k_scan_ranges<false, CAP>), grid, dim3(256), 0, c->stream, c->d_data, sn, c->d_q, B, c->d_perm_ct,
+                               c->d_perm_t, nchunks, slot_begin, slot_end, c->d_cand, c->d_cand_cnt, c->d_counters);
+    });
     kernel_timer_end(c, ev);
     const uint32_t nsel = slot_end - slot_begin;
-    uint64_t* cand = c->d_cand + (size_t)slot_begin * HVS_CAND_CAP;
+    uint64_t* cand = c->d_cand + (size_t)slot_begin * (size_t)c->cap;
     uint32_t* cnt = c->d_cand_cnt + slot_begin;
-    if (c->scalar_order)
-        hipLaunchKernelGGL(hvs_k_select<true>, dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           B.qid + slot_begin, nsel, B.nslots, nchunks, cand, cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
-    else
-        hipLaunchKernelGGL(hvs_k_select<false>, dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
-                           B.qid + slot_begin, nsel, B.nslots, nchunks, cand, cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists);
+    with_cap(c->cap, [&](auto CAPT) {
+        constexpr int CAP = decltype(CAPT)::value;
+        if (c->scalar_order)
+            hipLaunchKernelGGL((hvs_k_select<true, CAP>), dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                               B.qid + slot_begin, nsel, B.nslots, nchunks, cand, cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, c->k);
+        else
+            hipLaunchKernelGGL((hvs_k_select<false, CAP>), dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, c->n, c->d_q,
+                               B.qid + slot_begin, nsel, B.nslots, nchunks, cand, cnt, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, c->k);
+    });
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -681,16 +709,21 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
     uint32_t seed_chunks = 1u;
     if (l0blocks <= HVS_FCAP / 32u && seed_waves < 16384u) seed_chunks = std::min(l0blocks, hvs_ceil_div(16384u, seed_waves));
-    hipLaunchKernelGGL(hvs_k_seed_exact, dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0, c->stream,
-                       c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
-                       std::max(1u, seed_chunks));
+    with_cap(c->cap, [&](auto CAPT) {
+        hipLaunchKernelGGL((hvs_k_seed_exact<decltype(CAPT)::value>), dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0,
+                           c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
+                           std::max(1u, seed_chunks));
+    });
     auto launch_merge = [&](bool final) {
-        if (final)
-            hipLaunchKernelGGL(hvs_k_merge<true>, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                               c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
-        else
-            hipLaunchKernelGGL(hvs_k_merge<false>, dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                               c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+        with_cap(c->cap, [&](auto CAPT) {
+            constexpr int CAP = decltype(CAPT)::value;
+            if (final)
+                hipLaunchKernelGGL((hvs_k_merge<true, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+            else
+                hipLaunchKernelGGL((hvs_k_merge<false, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+        });
     };
     launch_merge(L.K == 0u);
     // re-scoring blocks per group: each block stages the group's 128 queries in LDS first, so large batches use
@@ -935,9 +968,9 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
 
 int begin_data(hvs_ctx* c, uint32_t n)
 {
-    if (n < HVS_KNN)
+    if (n < c->k)
         return fail(c, HVS_EINVAL,
-                    "data set needs at least 100 rows (the reference pads results with rows n-1, n-2, ...)");
+                    "data set needs at least k (default 100) rows (the reference pads results with rows n-1, n-2, ...)");
     HVS_HIP(c, hipSetDevice(c->device));
     int rc = resolve_overflow(c);
     if (rc) return rc;
@@ -987,15 +1020,24 @@ bool host_pointer_is_pinned(const void* p)
 // pinned staging slots of the host pipeline, allocated on first use (4 x (27 + 26 + 26) MB)
 int ensure_staging(hvs_ctx* c, bool dists)
 {
+    if (c->stage_k < c->k) {  // k grew (hvs_set_k): the result slots are too small
+        for (int i = 0; i < hvs_ctx::kRing; ++i) {
+            if (c->h_out_ids[i]) (void)hipHostFree(c->h_out_ids[i]);
+            if (c->h_out_dists[i]) (void)hipHostFree(c->h_out_dists[i]);
+            c->h_out_ids[i] = nullptr;
+            c->h_out_dists[i] = nullptr;
+        }
+        c->stage_k = c->k;
+    }
     for (int i = 0; i < hvs_ctx::kRing; ++i) {
         if (!c->h_in[i])
             HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_in[i]), (size_t)hvs_ctx::kStageQ * HVS_QCOLS * sizeof(float),
                                      hipHostMallocDefault));
         if (!c->h_out_ids[i])
-            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_ids[i]), (size_t)hvs_ctx::kStageQ * HVS_KNN * sizeof(uint32_t),
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_ids[i]), (size_t)hvs_ctx::kStageQ * c->stage_k * sizeof(uint32_t),
                                      hipHostMallocDefault));
         if (dists && !c->h_out_dists[i])
-            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_dists[i]), (size_t)hvs_ctx::kStageQ * HVS_KNN * sizeof(float),
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_dists[i]), (size_t)hvs_ctx::kStageQ * c->stage_k * sizeof(float),
                                      hipHostMallocDefault));
     }
     return HVS_OK;
@@ -1116,11 +1158,11 @@ int leaf_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_id
     if (!out_ids || (uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "hvs_download_results: bad range");
     int rc = leaf_sync(c);
     if (rc) return rc;
-    HVS_HIP(c, hipMemcpyAsync(out_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
+    HVS_HIP(c, hipMemcpyAsync(out_ids, c->d_out_ids + (size_t)q0 * c->k, (size_t)nq * c->k * sizeof(uint32_t),
                               hipMemcpyDeviceToHost, c->stream));
     if (out_dists)
-        HVS_HIP(c, hipMemcpyAsync(out_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
-                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipMemcpyAsync(out_dists, c->d_out_dists + (size_t)q0 * c->k,
+                                  (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     return HVS_OK;
 }
@@ -1173,19 +1215,19 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         const int k = (int)(out_drained % R);
         HVS_HIP(c, hipEventSynchronize(c->ev_out[k]));
         const uint32_t q0 = out_drained * SQ, m = std::min(SQ, nq - q0);
-        std::memcpy(out_ids + (size_t)q0 * HVS_KNN, c->h_out_ids[k], (size_t)m * HVS_KNN * sizeof(uint32_t));
-        if (out_dists) std::memcpy(out_dists + (size_t)q0 * HVS_KNN, c->h_out_dists[k], (size_t)m * HVS_KNN * sizeof(float));
+        std::memcpy(out_ids + (size_t)q0 * c->k, c->h_out_ids[k], (size_t)m * c->k * sizeof(uint32_t));
+        if (out_dists) std::memcpy(out_dists + (size_t)q0 * c->k, c->h_out_dists[k], (size_t)m * c->k * sizeof(float));
         ++out_drained;
         return HVS_OK;
     };
     auto copy_out_until = [&](uint32_t p1) -> int {
         for (; out_enq < p1; ++out_enq) {
             const uint32_t q0 = out_enq * SQ, m = std::min(SQ, nq - q0);
-            const size_t nb = (size_t)m * HVS_KNN * sizeof(uint32_t);
+            const size_t nb = (size_t)m * c->k * sizeof(uint32_t);
             if (out_pinned) {
-                HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)q0 * HVS_KNN, c->d_out_ids + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+                HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)q0 * c->k, c->d_out_ids + (size_t)q0 * c->k, nb, hipMemcpyDeviceToHost, c->s_out));
                 if (out_dists)
-                    HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)q0 * HVS_KNN, c->d_out_dists + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+                    HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)q0 * c->k, c->d_out_dists + (size_t)q0 * c->k, nb, hipMemcpyDeviceToHost, c->s_out));
                 continue;
             }
             if (out_enq - out_drained >= (uint32_t)R) {
@@ -1193,9 +1235,9 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
                 if (rc2) return rc2;
             }
             const int k = (int)(out_enq % R);
-            HVS_HIP(c, hipMemcpyAsync(c->h_out_ids[k], c->d_out_ids + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+            HVS_HIP(c, hipMemcpyAsync(c->h_out_ids[k], c->d_out_ids + (size_t)q0 * c->k, nb, hipMemcpyDeviceToHost, c->s_out));
             if (out_dists)
-                HVS_HIP(c, hipMemcpyAsync(c->h_out_dists[k], c->d_out_dists + (size_t)q0 * HVS_KNN, nb, hipMemcpyDeviceToHost, c->s_out));
+                HVS_HIP(c, hipMemcpyAsync(c->h_out_dists[k], c->d_out_dists + (size_t)q0 * c->k, nb, hipMemcpyDeviceToHost, c->s_out));
             HVS_HIP(c, hipEventRecord(c->ev_out[k], c->s_out));
         }
         return HVS_OK;
@@ -1236,11 +1278,11 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         std::vector<uint32_t> list(novf);
         HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t qi : list) {
-            HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * HVS_KNN, c->d_out_ids + (size_t)qi * HVS_KNN, HVS_KNN * sizeof(uint32_t),
+            HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * c->k, c->d_out_ids + (size_t)qi * c->k, c->k * sizeof(uint32_t),
                                       hipMemcpyDeviceToHost, c->stream));
             if (out_dists)
-                HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)qi * HVS_KNN, c->d_out_dists + (size_t)qi * HVS_KNN,
-                                          HVS_KNN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)qi * c->k, c->d_out_dists + (size_t)qi * c->k,
+                                          c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         }
         HVS_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -1466,6 +1508,33 @@ int hvs_set_distance_order(hvs_ctx* c, int order)
     return HVS_OK;
 }
 
+int hvs_set_k(hvs_ctx* c, uint32_t k)
+{
+    if (!c) return HVS_EINVAL;
+    if (k < 8u || k > HVS_KMAX) return fail(c, HVS_EINVAL, "hvs_set_k: k outside 8..256 (the reference asserts KNN_LIMIT >= 8)");
+    if (!c->kids.empty()) {
+        const int rc = for_each_leaf(c, [&](uint32_t r) { return hvs_set_k(c->kids[r], k); });
+        if (!rc) c->k = k;
+        return rc;
+    }
+    if (c->n && c->n < k) return fail(c, HVS_EINVAL, "hvs_set_k: the loaded data set has fewer than k rows");
+    if (k == c->k) return HVS_OK;
+    HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipStreamSynchronize(c->stream));
+    c->k = k;
+    c->cap = k <= 128u ? 256 : 512;
+    // result rows change size: resident queries stay, their results do not; list workspaces are re-sized on demand
+    const uint32_t had = c->res_cap;
+    c->res_cap = 0;
+    c->cand_lists = 0;
+    c->timing_valid = false;
+    return had ? ensure_results(c, had) : HVS_OK;
+}
+
+uint32_t hvs_get_k(const hvs_ctx* c) { return c ? c->k : 0u; }
+
 uint32_t hvs_num_rows(const hvs_ctx* c) { return !c ? 0u : (c->kids.empty() ? c->n : c->kids[0]->n); }
 
 int hvs_reserve(hvs_ctx* c, uint32_t nq)
@@ -1577,7 +1646,7 @@ int hvs_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_ids
     if (!c->kids.empty()) {
         if (!out_ids) return fail(c, HVS_EINVAL, "hvs_download_results: out_ids is NULL");
         return for_each_resident_part(c, q0, nq, [&](hvs_ctx* k, uint32_t lq0, uint32_t m, uint32_t off) {
-            return leaf_download_results(k, lq0, m, out_ids + (size_t)off * HVS_KNN, out_dists ? out_dists + (size_t)off * HVS_KNN : nullptr);
+            return leaf_download_results(k, lq0, m, out_ids + (size_t)off * c->k, out_dists ? out_dists + (size_t)off * c->k : nullptr);
         });
     }
     return leaf_download_results(c, q0, nq, out_ids, out_dists);
@@ -1591,11 +1660,11 @@ int hvs_export_results_device(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* d_
     HVS_HIP(c, hipSetDevice(c->device));
     int rc = resolve_overflow(c);
     if (rc) return rc;
-    HVS_HIP(c, hipMemcpyAsync(d_ids, c->d_out_ids + (size_t)q0 * HVS_KNN, (size_t)nq * HVS_KNN * sizeof(uint32_t),
+    HVS_HIP(c, hipMemcpyAsync(d_ids, c->d_out_ids + (size_t)q0 * c->k, (size_t)nq * c->k * sizeof(uint32_t),
                               hipMemcpyDeviceToDevice, c->stream));
     if (d_dists)
-        HVS_HIP(c, hipMemcpyAsync(d_dists, c->d_out_dists + (size_t)q0 * HVS_KNN,
-                                  (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HVS_HIP(c, hipMemcpyAsync(d_dists, c->d_out_dists + (size_t)q0 * c->k,
+                                  (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return HVS_OK;
 }
 
@@ -1620,8 +1689,8 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
                 c->kids[r]->timing_valid = false;
                 return HVS_OK;
             }
-            return leaf_query(c->kids[r], q_rows + (size_t)a * HVS_QCOLS, m, sample_proportion, out_ids + (size_t)a * HVS_KNN,
-                              out_dists ? out_dists + (size_t)a * HVS_KNN : nullptr);
+            return leaf_query(c->kids[r], q_rows + (size_t)a * HVS_QCOLS, m, sample_proportion, out_ids + (size_t)a * c->k,
+                              out_dists ? out_dists + (size_t)a * c->k : nullptr);
         });
     } else {
         // peer gather (A/B partner): every GPU answers its resident slice, the blocks of ids travel GPU -> GPU 0 over
@@ -1645,16 +1714,16 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
                 const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
                 hvs_ctx* k = c->kids[r];
                 if (m == 0u) continue;
-                if (hipMemcpyPeerAsync(k0->d_out_ids + (size_t)a * HVS_KNN, k0->device, k->d_out_ids, k->device,
-                                       (size_t)m * HVS_KNN * sizeof(uint32_t), k0->stream) != hipSuccess ||
-                    (out_dists && hipMemcpyPeerAsync(k0->d_out_dists + (size_t)a * HVS_KNN, k0->device, k->d_out_dists, k->device,
-                                                     (size_t)m * HVS_KNN * sizeof(float), k0->stream) != hipSuccess))
+                if (hipMemcpyPeerAsync(k0->d_out_ids + (size_t)a * c->k, k0->device, k->d_out_ids, k->device,
+                                       (size_t)m * c->k * sizeof(uint32_t), k0->stream) != hipSuccess ||
+                    (out_dists && hipMemcpyPeerAsync(k0->d_out_dists + (size_t)a * c->k, k0->device, k->d_out_dists, k->device,
+                                                     (size_t)m * c->k * sizeof(float), k0->stream) != hipSuccess))
                     rc = fail(c, HVS_EHIP, "hvs_query: peer copy of a result block failed");
             }
             if (!rc) {
                 (void)hipSetDevice(k0->device);
-                if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * HVS_KNN * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
-                    (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * HVS_KNN * sizeof(float), hipMemcpyDeviceToHost,
+                if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * c->k * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
+                    (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToHost,
                                                  k0->stream) != hipSuccess) ||
                     hipStreamSynchronize(k0->stream) != hipSuccess)
                     rc = fail(c, HVS_EHIP, "hvs_query: download of the gathered results failed");
@@ -1672,8 +1741,8 @@ int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uin
     if (!c) return HVS_EINVAL;
     if (!c->kids.empty()) return fail(c, HVS_EINVAL, "hvs_merge_shards_device: single-GPU contexts only");
     if (!d_ids_all || !d_dists_all || !shard_row0 || !d_pad_dists || !d_out_ids || nshards == 0u || nshards > 16u ||
-        n_total < HVS_KNN)
-        return fail(c, HVS_EINVAL, "hvs_merge_shards_device: bad argument (1..16 shards, n_total >= 100, non-NULL buffers)");
+        n_total < c->k)
+        return fail(c, HVS_EINVAL, "hvs_merge_shards_device: bad argument (1..16 shards, n_total >= k, non-NULL buffers)");
     if (nq == 0u) return HVS_OK;
     HVS_HIP(c, hipSetDevice(c->device));
     HvsShardRows rows{};
@@ -1681,8 +1750,10 @@ int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uin
         if (shard_row0[s] >= n_total) return fail(c, HVS_EINVAL, "hvs_merge_shards_device: shard row offset outside the data set");
         rows.row0[s] = shard_row0[s];
     }
-    hipLaunchKernelGGL(hvs_k_merge_shards, dim3((nq + 3u) / 4u), dim3(256), 0, c->stream, d_ids_all, d_dists_all, nshards, nq, rows,
-                       n_total, d_pad_dists, d_out_ids, d_out_dists);
+    with_cap(c->cap, [&](auto CAPT) {
+        hipLaunchKernelGGL((hvs_k_merge_shards<decltype(CAPT)::value>), dim3((nq + 3u) / 4u), dim3(256), 0, c->stream, d_ids_all, d_dists_all,
+                           nshards, nq, rows, n_total, d_pad_dists, d_out_ids, d_out_dists, c->k);
+    });
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }

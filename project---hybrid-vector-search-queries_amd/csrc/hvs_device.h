@@ -11,7 +11,8 @@
 #define HVS_DCOLS 102
 #define HVS_QCOLS 104
 #define HVS_NDIM 100
-#define HVS_KNN 100
+#define HVS_KNN 100     // default k (the reference's KNN_LIMIT, optimized_impl.h:26); hvs_set_k changes it per context
+#define HVS_KMAX 256    // largest k: lists of 64 NK keys with NK = 4 (k <= 128) or 8 (k <= 256)
 #define HVS_WAVE 64
 
 // ---------------------------------------------------------------------------------------------
@@ -178,18 +179,20 @@ __device__ __forceinline__ uint32_t hvs_prefix_count(uint64_t mask)
 // (`hist`, 256 x u32), one wave-wide prefix scan to find the bucket that holds the KEEP-th key, repeat inside that
 // bucket.  Distances of one query's candidates separate within ~3 digits below their common prefix, against
 // ~25 single-bit steps of 4 ballots each: the merge kernels spend 5-6x fewer instructions here.
-template <int KEEP>
-__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t lane, uint32_t* hist)
+// NK = keys per lane: the list holds at most 64 NK keys (256 for k <= 128, 512 for k <= 256); `keep` = k at run time.
+template <int NK>
+__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t keep, uint32_t lane, uint32_t* hist)
 {
-    uint64_t k[4];
-    bool act[4];
+    uint64_t k[NK];
+    bool act[NK];
+    bool valid[NK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NK; ++i) {
         const uint32_t idx = lane + 64u * i;
         act[i] = idx < cnt;
+        valid[i] = act[i];
         k[i] = act[i] ? list[idx] : ~0ull;
     }
-    const bool valid0 = act[0], valid1 = act[1], valid2 = act[2], valid3 = act[3];
     // common prefix of all keys (see the bit-serial version)
     int hi;
     uint64_t prefix;
@@ -197,7 +200,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         const uint64_t k0 = list[0];
         uint64_t d = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d |= act[i] ? (k[i] ^ k0) : 0ull;
+        for (int i = 0; i < NK; ++i) d |= act[i] ? (k[i] ^ k0) : 0ull;
         uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -208,7 +211,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         hi = d ? 63 - (int)__builtin_clzll(d) : 0;
         prefix = hi < 63 ? (k0 & (~0ull << (hi + 1))) : 0ull;
     }
-    uint32_t r = KEEP;  // rank of the wanted key inside the active set
+    uint32_t r = keep;  // rank of the wanted key inside the active set
     for (;;) {          // wave-uniform
         const int lo = hi >= 7 ? hi - 7 : 0;
         const uint32_t dmask = (1u << (hi - lo + 1)) - 1u;
@@ -216,7 +219,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         for (int i = 0; i < 4; ++i) hist[lane + 64u * i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NK; ++i)
             if (act[i]) atomicAdd(&hist[(uint32_t)(k[i] >> lo) & dmask], 1u);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // lane l owns buckets 4l .. 4l+3
@@ -243,11 +246,11 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         r -= before;
         prefix |= (uint64_t)digit << lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) act[i] = act[i] && (((uint32_t)(k[i] >> lo) & dmask) == digit);
+        for (int i = 0; i < NK; ++i) act[i] = act[i] && (((uint32_t)(k[i] >> lo) & dmask) == digit);
         if (rem == 1u) {
             // one key left under this prefix: it is the answer (keys are distinct)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NK; ++i) {
                 const uint64_t mm = __ballot(act[i]);
                 if (mm != 0ull) {
                     const int s2 = (int)__builtin_ctzll(mm);
@@ -262,30 +265,29 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         hi = lo - 1;
     }
     uint32_t base = 0;
-    const bool valid[4] = {valid0, valid1, valid2, valid3};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool keep = valid[i] && k[i] <= prefix;
-        const uint64_t mask = __ballot(keep);
-        if (keep) list[base + hvs_prefix_count(mask)] = k[i];
+    for (int i = 0; i < NK; ++i) {
+        const bool kp = valid[i] && k[i] <= prefix;
+        const uint64_t mask = __ballot(kp);
+        if (kp) list[base + hvs_prefix_count(mask)] = k[i];
         base += (uint32_t)__popcll(mask);
     }
     return prefix;
 }
 
-template <int KEEP>
-__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t lane)
+template <int NK>
+__device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t keep, uint32_t lane)
 {
-    uint64_t k[4];
-    bool valid[4];
+    uint64_t k[NK];
+    bool valid[NK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NK; ++i) {
         const uint32_t idx = lane + 64u * i;
         valid[i] = idx < cnt;
         k[i] = valid[i] ? list[idx] : ~0ull;
     }
     uint64_t prefix = 0;
-    uint32_t r = KEEP;
+    uint32_t r = keep;
     uint32_t rem = cnt;  // keys that still match the decided prefix bits
     // Bits above the highest bit in which any two keys differ are common to all keys (distances of one query's
     // candidates share sign, exponent and often the first mantissa bits): they go into the prefix without a
@@ -295,7 +297,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         const uint64_t k0 = list[0];  // cnt > KEEP >= 1: a valid key
         uint64_t d = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d |= valid[i] ? (k[i] ^ k0) : 0ull;
+        for (int i = 0; i < NK; ++i) d |= valid[i] ? (k[i] ^ k0) : 0ull;
         uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -311,7 +313,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         const uint64_t himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
         uint32_t c0 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NK; ++i) {
             const bool m = valid[i] && (((k[i] ^ prefix) & himask) == 0ull) && (((k[i] >> bit) & 1ull) == 0ull);
             c0 += (uint32_t)__popcll(__ballot(m));
         }
@@ -327,7 +329,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
             // the remaining bits (distances usually separate within the first ~25 bits)
             const uint64_t lomask = ~0ull << bit;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NK; ++i) {
                 const uint64_t mm = __ballot(valid[i] && (((k[i] ^ prefix) & lomask) == 0ull));
                 if (mm != 0ull) {
                     const int src = (int)__builtin_ctzll(mm);
@@ -341,10 +343,10 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
     }
     uint32_t base = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool keep = valid[i] && k[i] <= prefix;
-        const uint64_t mask = __ballot(keep);
-        if (keep) list[base + hvs_prefix_count(mask)] = k[i];
+    for (int i = 0; i < NK; ++i) {
+        const bool kp = valid[i] && k[i] <= prefix;
+        const uint64_t mask = __ballot(kp);
+        if (kp) list[base + hvs_prefix_count(mask)] = k[i];
         base += (uint32_t)__popcll(mask);
     }
     return prefix;

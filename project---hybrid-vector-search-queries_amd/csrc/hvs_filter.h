@@ -60,7 +60,6 @@
 #ifndef HVS_FILTER_OCC
 #define HVS_FILTER_OCC 2      // waves per SIMD the filter kernel is compiled for
 #endif
-#define HVS_TOPCAP 128        // stored top list stride
 #ifndef HVS_RESCORE_WAVES
 #define HVS_RESCORE_WAVES 8    // waves per re-scoring block (they share the group's queries in LDS)
 #endif
@@ -594,7 +593,9 @@ struct HvsBatch {
     float* eq;                  // [nslots] |q - bf16(q)| (rounded up)
     float* nqb;                 // [nslots] |bf16(q)| (rounded up)
     // top-k state
-    uint64_t* top;              // [nslots][HVS_TOPCAP]
+    uint64_t* top;              // [nslots][topcap]
+    uint32_t topcap;            // stride of the stored top-k lists: 128 (k <= 128) or 256
+    uint32_t knn;               // k of this batch (hvs_set_k; the reference's KNN_LIMIT, optimized_impl.h:26)
     uint32_t* topcnt;           // [nslots]
     float* tau;                 // [nslots]
     uint64_t* cand;             // [nslots][HVS_FCAP]
@@ -944,6 +945,7 @@ struct HvsUniformRowF2 {
     __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
 };
 
+template <int CAP>
 __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restrict__ D, uint32_t n, uint32_t sn,
                                                            const float* __restrict__ Q, HvsBatch B,
                                                            const uint32_t* __restrict__ perm_ct,
@@ -1008,16 +1010,16 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
                 mylist[cnt] = hvs_make_key(dist, id);
                 ++cnt;
             }
-            uint64_t full = __ballot(cnt == 256u);
+            uint64_t full = __ballot(cnt == (uint32_t)CAP);
             if (full != 0ull) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 while (full != 0ull) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(full);
                     full &= full - 1ull;
                     uint64_t* lst = B.cand + (size_t)(w * 64u + l) * HVS_FCAP;
-                    const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, 256u, lane);
+                    const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, B.knn, lane);
                     if (lane == l) {
-                        cnt = HVS_KNN;
+                        cnt = B.knn;
                         tau = hvs_key_dist(kth);
                     }
                 }
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
 // type-2 wave touches only rows that some of its queries want.  grid.y cuts the range into chunks.
 // With sn < n (sample_proportion < 1) rows whose original id is >= sn are skipped.
 // ---------------------------------------------------------------------------------------------
-template <bool SCALAR_ORDER>
+template <bool SCALAR_ORDER, int CAP>
 __global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restrict__ D, uint32_t sn,
                                                             const float* __restrict__ Q, HvsBatch B,
                                                             const uint32_t* __restrict__ perm_ct,
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restr
         q2[2 * i] = hvs_f2{v4.x, v4.y};
         q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
     }
-    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * B.nslots + slot) * 256u;
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * B.nslots + slot) * (uint32_t)CAP;
     float tau = __builtin_nanf("");  // admits every passing row until the first cut (see hvs_k_scan_exact)
     uint32_t cnt = 0, nscan = 0;
     for (uint32_t pos = p0; pos < p1; ++pos) {
@@ -1105,16 +1107,16 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_ranges(const float* __restr
             mylist[cnt] = hvs_make_key(dist, id);
             ++cnt;
         }
-        uint64_t full = __ballot(cnt == 256u);
+        uint64_t full = __ballot(cnt == (uint32_t)CAP);
         if (full != 0ull) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             while (full != 0ull) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(full);
                 full &= full - 1ull;
-                uint64_t* lst = cand + ((size_t)chunk * B.nslots + (w * 64u + l)) * 256u;
-                const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, 256u, lane);
+                uint64_t* lst = cand + ((size_t)chunk * B.nslots + (w * 64u + l)) * (uint32_t)CAP;
+                const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, B.knn, lane);
                 if (lane == l) {
-                    cnt = HVS_KNN;
+                    cnt = B.knn;
                     tau = hvs_key_dist(kth);
                 }
             }
@@ -2021,17 +2023,18 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
 // ---------------------------------------------------------------------------------------------
 // (FINAL as a template parameter: the padding path's exact-order distance costs 70 VGPRs that would halve the
 // occupancy of the 13 latency-bound merges before it)
-template <bool FINAL>
+template <bool FINAL, int CAP>
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
                                                    HvsBatch B, const HvsBounds* __restrict__ bounds, int pad,
                                                    uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, int fmt,
                                                    const HvsQuant* __restrict__ qz)
 {
-    __shared__ uint64_t sbuf[4][256];
+    __shared__ uint64_t sbuf[4][CAP];
     __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4u + w;
+    const uint32_t knn = B.knn;
     if (slot >= B.nslots) return;
     const uint32_t qi = B.qid[slot];
     if (qi == 0xFFFFFFFFu) return;
@@ -2040,13 +2043,13 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     if (m > HVS_FCAP) m = HVS_FCAP;
     if (m == 0u && !FINAL) return;  // nothing new at this level: top-100, tau and theta stand
     uint32_t cnt = B.topcnt[slot];
-    for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * HVS_TOPCAP + e];
+    for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * B.topcap + e];
     const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
     for (uint32_t off = 0; off < m; off += 64u) {
-        if (cnt + 64u > 256u) {
+        if (cnt + 64u > (uint32_t)CAP) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-            cnt = HVS_KNN;
+            hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+            cnt = knn;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
         const uint32_t take = (m - off) < 64u ? (m - off) : 64u;
@@ -2054,13 +2057,13 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         cnt += take;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-        cnt = HVS_KNN;
+    if (cnt > knn) {
+        hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+        cnt = knn;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     if constexpr (!FINAL) {
-        for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * HVS_TOPCAP + e] = buf[e];
+        for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * B.topcap + e] = buf[e];
         // tau = largest kept distance once 100 are held
         float dmax = 0.0f;
         for (uint32_t e = lane; e < cnt; e += 64u) dmax = fmaxf(dmax, hvs_key_dist(buf[e]));
@@ -2074,7 +2077,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
             if (HVS_IS_I8(fmt)) {
                 // INT8 formats (see "INT8 filter" above): S = qq.dq + nh is exact, the band has no accumulation term
                 int ti = B.rb[slot] > B.ra[slot] ? (int)0x80000000 : 0x7FFFFFFF;
-                if (cnt >= HVS_KNN) {
+                if (cnt >= knn) {
                     tau = dmax;
                     const double g = 20.0 * 5.9604644775390625e-08;
                     const double iu = qz->inv_sd * qz->inv_sd;  // 1 / sd^2
@@ -2092,7 +2095,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                 B.thetai[slot] = ti;
                 return;
             }
-            if (cnt >= HVS_KNN) {
+            if (cnt >= knn) {
                 tau = dmax;
                 const double g = 20.0 * 5.9604644775390625e-08;
                 const double sabs = (double)B.nqb[slot] * (double)bounds->nb_d + 1.02 * (double)bounds->hmax;
@@ -2117,9 +2120,9 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     }
     // ---- final: pad, rank-sort, write
     const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
-    for (uint32_t base = cnt; base < HVS_KNN; base += 64u) {
+    for (uint32_t base = cnt; base < knn; base += 64u) {
         const uint32_t e = base + lane;
-        if (e < HVS_KNN) {
+        if (e < knn) {
             const uint32_t id = n - 1u - (e - cnt);
             const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
             // padding off (partial answers of a data shard): empty slots hold the largest key
@@ -2127,15 +2130,15 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+    for (uint32_t e = lane; e < knn; e += 64u) {
         const uint64_t ke = buf[e];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+        for (uint32_t j = 0; j < knn; ++j) {
             const uint64_t kj = buf[j];
             rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
         }
-        out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
-        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
+        out_ids[(size_t)qi * knn + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)qi * knn + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
 }
 

@@ -4,7 +4,8 @@
 #include "hvs_device.h"
 #include "../../include/hvs_gen.h"
 
-#define HVS_CAND_CAP 256  // per (query, row-chunk) candidate list capacity (keys)
+// per (query, row-chunk) candidate list capacity (keys): kernels are instantiated for CAP = 256 (k <= 128) and
+// CAP = 512 (k <= 256); k itself is a run-time argument
 
 // ---------------------------------------------------------------------------------------------
 // Synthetic inputs generated in HBM (include/hvs_gen.h), one thread per element.
@@ -92,11 +93,11 @@ struct HvsPairAsScalar {  // view the lane's 50 query pairs as 100 floats
 
 // SCALAR_ORDER = false: the hot path's SIMD summation order (optimized_impl.h:96-125);
 // SCALAR_ORDER = true : the baseline engine's sequential order (baseline.hpp:53-64), BASELINE.json configs[0].
-template <bool SCALAR_ORDER>
+template <bool SCALAR_ORDER, int CAP>
 __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-    unsigned long long* __restrict__ counters)
+    unsigned long long* __restrict__ counters, uint32_t knn)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t qwave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
     uint32_t r1 = r0 + rows_per_chunk;
     if (r1 > sn || r1 < r0) r1 = sn;
 
-    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * CAP;
     // tau = NaN until the list has been cut back once: `!(dist >= tau)` then admits EVERY passing row, +inf and NaN
     // distances included, as the reference does while its list is not full (optimized_impl.h:301-304)
     float tau = __builtin_nanf("");
@@ -153,16 +154,16 @@ __global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
             mylist[cnt] = hvs_make_key(dist, j);
             ++cnt;
         }
-        uint64_t full = __ballot(cnt == HVS_CAND_CAP);
+        uint64_t full = __ballot(cnt == (uint32_t)CAP);
         if (full != 0ull) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             while (full != 0ull) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(full);
                 full &= full - 1ull;
-                uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * HVS_CAND_CAP;
-                const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, HVS_CAND_CAP, lane);
+                uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * CAP;
+                const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, knn, lane);
                 if (lane == l) {
-                    cnt = HVS_KNN;
+                    cnt = knn;
                     tau = hvs_key_dist(kth);
                 }
             }
@@ -200,11 +201,11 @@ struct HvsLdsRow1 {
     __device__ __forceinline__ float operator[](int i) const { return p[i]; }
 };
 
-template <bool SCALAR_ORDER>
+template <bool SCALAR_ORDER, int CAP>
 __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-    unsigned long long* __restrict__ counters)
+    unsigned long long* __restrict__ counters, uint32_t knn)
 {
     __shared__ float4 srow[2][HVS_LDS_ROWS * HVS_LDS_ROW_F / 4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
         }
     };
 
-    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * HVS_CAND_CAP;
+    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * CAP;
     float tau = __builtin_nanf("");  // (see hvs_k_scan_exact)
     uint32_t cnt = 0;
     uint32_t npass = 0, nscan = 0;
@@ -298,16 +299,16 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
                     mylist[cnt] = hvs_make_key(dist, j0 + r);
                     ++cnt;
                 }
-                uint64_t full = __ballot(cnt == HVS_CAND_CAP);
+                uint64_t full = __ballot(cnt == (uint32_t)CAP);
                 if (full != 0ull) {
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     while (full != 0ull) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(full);
                         full &= full - 1ull;
-                        uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * HVS_CAND_CAP;
-                        const uint64_t kth = hvs_wave_select_prune<HVS_KNN>(lst, HVS_CAND_CAP, lane);
+                        uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 64u + l)) * CAP;
+                        const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, knn, lane);
                         if (lane == l) {
-                            cnt = HVS_KNN;
+                            cnt = knn;
                             tau = hvs_key_dist(kth);
                         }
                     }
@@ -334,13 +335,13 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
 // emit ids in ascending (dist, id) order (get_knn_sorted, optimized_impl.h:392-415).
 // One wave per query, 4 queries per 256-thread block, a 256-key LDS buffer per wave.
 // ---------------------------------------------------------------------------------------------
-template <bool SCALAR_ORDER>
+template <bool SCALAR_ORDER, int CAP>
 __global__ __launch_bounds__(256) void hvs_k_select(
     const float* __restrict__ D, uint32_t n, const float* __restrict__ Q, const uint32_t* __restrict__ qorder,
     uint32_t nq, uint32_t nq_pad, uint32_t nchunks, const uint64_t* __restrict__ cand,
-    const uint32_t* __restrict__ cand_cnt, int pad, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+    const uint32_t* __restrict__ cand_cnt, int pad, uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, uint32_t knn)
 {
-    __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    __shared__ uint64_t sbuf[4][CAP];
     __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
@@ -353,12 +354,12 @@ __global__ __launch_bounds__(256) void hvs_k_select(
     uint32_t cnt = 0;
     for (uint32_t c = 0; c < nchunks; ++c) {
         const uint32_t m = cand_cnt[(size_t)c * nq_pad + slot];
-        const uint64_t* __restrict__ lst = cand + ((size_t)c * nq_pad + slot) * HVS_CAND_CAP;
+        const uint64_t* __restrict__ lst = cand + ((size_t)c * nq_pad + slot) * CAP;
         for (uint32_t off = 0; off < m; off += 64u) {
-            if (cnt + 64u > HVS_CAND_CAP) {
+            if (cnt + 64u > (uint32_t)CAP) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-                cnt = HVS_KNN;
+                hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+                cnt = knn;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
             const uint32_t take = (m - off) < 64u ? (m - off) : 64u;
@@ -367,16 +368,16 @@ __global__ __launch_bounds__(256) void hvs_k_select(
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-        cnt = HVS_KNN;
+    if (cnt > knn) {
+        hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+        cnt = knn;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     // padding: fewer than 100 matching rows in [0,sn)
     const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
-    for (uint32_t base = cnt; base < HVS_KNN; base += 64u) {
+    for (uint32_t base = cnt; base < knn; base += 64u) {
         const uint32_t e = base + lane;
-        if (e < HVS_KNN) {
+        if (e < knn) {
             const uint32_t id = n - 1u - (e - cnt);
             const float* __restrict__ dv = D + (size_t)id * HVS_DCOLS + 2;
             buf[e] = pad ? hvs_make_key(SCALAR_ORDER ? hvs_scalar_order_dist(dv, qv) : hvs_exact_dist(dv, qv), id) : ~0ull;
@@ -384,15 +385,15 @@ __global__ __launch_bounds__(256) void hvs_k_select(
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     // rank sort of exactly 100 keys (duplicates possible after padding: ties broken by slot)
-    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+    for (uint32_t e = lane; e < knn; e += 64u) {
         const uint64_t ke = buf[e];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+        for (uint32_t j = 0; j < knn; ++j) {
             const uint64_t kj = buf[j];
             rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
         }
-        out_ids[(size_t)qi * HVS_KNN + rank] = hvs_key_id(ke);
-        if (out_dists) out_dists[(size_t)qi * HVS_KNN + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
+        out_ids[(size_t)qi * knn + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)qi * knn + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
 }
 
@@ -409,13 +410,14 @@ struct HvsShardRows {
     uint64_t row0[16];  // first global row of each shard
 };
 
+template <int CAP>
 __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __restrict__ ids_all,
                                                           const float* __restrict__ dists_all, uint32_t nshards,
                                                           uint32_t nq, HvsShardRows rows, uint32_t n_total,
                                                           const float* __restrict__ pad_dists,
-                                                          uint32_t* __restrict__ out_ids, float* __restrict__ out_dists)
+                                                          uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, uint32_t knn)
 {
-    __shared__ uint64_t sbuf[4][HVS_CAND_CAP];
+    __shared__ uint64_t sbuf[4][CAP];
     __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
@@ -424,16 +426,16 @@ __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __rest
     uint64_t* buf = sbuf[w];
     uint32_t cnt = 0;
     for (uint32_t s = 0; s < nshards; ++s) {
-        const size_t base = ((size_t)s * nq + q) * HVS_KNN;
-        for (uint32_t off = 0; off < HVS_KNN; off += 64u) {
-            if (cnt + 64u > HVS_CAND_CAP) {
+        const size_t base = ((size_t)s * nq + q) * knn;
+        for (uint32_t off = 0; off < knn; off += 64u) {
+            if (cnt + 64u > (uint32_t)CAP) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-                cnt = HVS_KNN;
+                hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+                cnt = knn;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
             const uint32_t e = off + lane;
-            const uint32_t id = e < HVS_KNN ? ids_all[base + e] : 0xFFFFFFFFu;
+            const uint32_t id = e < knn ? ids_all[base + e] : 0xFFFFFFFFu;
             const bool have = id != 0xFFFFFFFFu;
             const uint64_t m = __ballot(have);
             if (have) buf[cnt + hvs_prefix_count(m)] = hvs_make_key(dists_all[base + e], (uint32_t)(rows.row0[s] + id));
@@ -441,26 +443,26 @@ __global__ __launch_bounds__(256) void hvs_k_merge_shards(const uint32_t* __rest
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (cnt > HVS_KNN) {
-        hvs_wave_select_prune<HVS_KNN>(buf, cnt, lane, shist[w]);
-        cnt = HVS_KNN;
+    if (cnt > knn) {
+        hvs_wave_select_prune<CAP / 64>(buf, cnt, knn, lane, shist[w]);
+        cnt = knn;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-    for (uint32_t b = cnt; b < HVS_KNN; b += 64u) {
+    for (uint32_t b = cnt; b < knn; b += 64u) {
         const uint32_t e = b + lane;
-        if (e < HVS_KNN) buf[e] = hvs_make_key(pad_dists[(size_t)q * HVS_KNN + (e - cnt)], n_total - 1u - (e - cnt));
+        if (e < knn) buf[e] = hvs_make_key(pad_dists[(size_t)q * knn + (e - cnt)], n_total - 1u - (e - cnt));
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     // rank sort of exactly 100 keys (duplicates possible after padding: ties broken by slot)
-    for (uint32_t e = lane; e < HVS_KNN; e += 64u) {
+    for (uint32_t e = lane; e < knn; e += 64u) {
         const uint64_t ke = buf[e];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < HVS_KNN; ++j) {
+        for (uint32_t j = 0; j < knn; ++j) {
             const uint64_t kj = buf[j];
             rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u;
         }
-        out_ids[(size_t)q * HVS_KNN + rank] = hvs_key_id(ke);
-        if (out_dists) out_dists[(size_t)q * HVS_KNN + rank] = hvs_key_dist(ke);
+        out_ids[(size_t)q * knn + rank] = hvs_key_id(ke);
+        if (out_dists) out_dists[(size_t)q * knn + rank] = hvs_key_dist(ke);
     }
 }
 

@@ -133,6 +133,8 @@ def library():
         "hvs_set_engine": (C.c_int, [vp, C.c_int]),
         "hvs_set_distance_order": (C.c_int, [vp, C.c_int]),
         "hvs_set_padding": (C.c_int, [vp, C.c_int]),
+        "hvs_set_k": (C.c_int, [vp, C.c_uint32]),
+        "hvs_get_k": (C.c_uint32, [vp]),
         "hvs_load_data": (C.c_int, [vp, _f32p, C.c_uint32]),
         "hvs_gen_data": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32]),
         "hvs_download_data": (C.c_int, [vp, C.c_uint32, C.c_uint32, _f32p]),
@@ -219,6 +221,14 @@ class Engine:
         """0 = the hot path's SIMD order (default), 1 = the baseline engine's sequential order."""
         self._ck(self._lib.hvs_set_distance_order(self._h, order))
 
+    def set_k(self, k):
+        """Neighbours per query (the reference's compile-time KNN_LIMIT): 8..256, default 100."""
+        self._ck(self._lib.hvs_set_k(self._h, int(k)))
+
+    @property
+    def k(self):
+        return int(self._lib.hvs_get_k(self._h))
+
     def set_padding(self, enabled):
         """Off: answers of a data shard keep id 0xFFFFFFFF / distance +inf in unmatched slots."""
         self._ck(self._lib.hvs_set_padding(self._h, int(bool(enabled))))
@@ -249,13 +259,13 @@ class Engine:
         q = np.ascontiguousarray(q_rows, np.float32)
         if q.ndim != 2 or q.shape[1] != QCOLS:
             raise HvsError(-1, "query rows must be nq x 104 float32")
-        nq = q.shape[0]
+        nq, K = q.shape[0], self.k
         ids = out_ids if out_ids is not None else np.empty((nq, K), np.uint32)
         d = out_dists if out_dists is not None else (np.empty((nq, K), np.float32) if want_dists else None)
         if ids.shape != (nq, K) or ids.dtype != np.uint32 or not ids.flags.c_contiguous:
-            raise HvsError(-1, "out_ids must be a C-contiguous nq x 100 uint32 array")
+            raise HvsError(-1, "out_ids must be a C-contiguous nq x k uint32 array")
         if d is not None and (d.shape != (nq, K) or d.dtype != np.float32 or not d.flags.c_contiguous):
-            raise HvsError(-1, "out_dists must be a C-contiguous nq x 100 float32 array")
+            raise HvsError(-1, "out_dists must be a C-contiguous nq x k float32 array")
         self._ck(self._lib.hvs_query(self._h, _fp(q), nq, sample_proportion, _up(ids), _fp(d) if d is not None else None))
         return (ids, d) if d is not None else ids
 
@@ -279,6 +289,7 @@ class Engine:
         self._ck(self._lib.hvs_sync(self._h))
 
     def download_results(self, q0, nq, want_dists=True):
+        K = self.k
         ids = np.empty((nq, K), np.uint32)
         d = np.empty((nq, K), np.float32) if want_dists else None
         self._ck(self._lib.hvs_download_results(self._h, q0, nq, _up(ids), _fp(d) if want_dists else None))

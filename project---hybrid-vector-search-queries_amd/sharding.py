@@ -75,14 +75,15 @@ def merge_data_shards(parts, n_total: int, pad_dists):
     """parts: list of (ids_local [nq,100] u32, dists [nq,100] f32, row0) -- one per shard, padding off.
     pad_dists: [nq,100] f32, pad_dists[q, s] = exact-order distance of query q to row n_total-1-s.
     Returns (ids [nq,100] u32 global, dists [nq,100] f32) in the canonical order (dist asc, id asc)."""
+    k = np.asarray(parts[0][0]).shape[1]            # 100 unless the contexts were given another k (hvs_set_k)
     allk = np.concatenate([_keys(i, d, r0) for i, d, r0 in parts], axis=1)
     allk.sort(axis=1)
-    best = allk[:, :100].copy()
+    best = allk[:, :k].copy()
     m = (best != _EMPTY_KEY).sum(axis=1)
-    pad_ids = (np.uint64(n_total - 1) - np.arange(100, dtype=np.uint64))[None, :]
+    pad_ids = (np.uint64(n_total - 1) - np.arange(k, dtype=np.uint64))[None, :]
     padk = (np.ascontiguousarray(pad_dists, np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | pad_ids
-    for q in np.nonzero(m < 100)[0]:
-        need = 100 - int(m[q])
+    for q in np.nonzero(m < k)[0]:
+        need = k - int(m[q])
         row = np.concatenate([best[q, : m[q]], padk[q, :need]])  # rows n-1, n-2, ... regardless of duplicates
         row.sort()
         best[q] = row
@@ -92,16 +93,16 @@ def merge_data_shards(parts, n_total: int, pad_dists):
 
 
 def tail_pad_dists(answer_tail, queries):
-    """Distances of every query to the last 100 rows of the whole data set.  `answer_tail(q_rows)`
-    answers against a data set made of exactly those 100 rows (ids 0..99 = rows n-100..n-1); the
-    queries' predicates are stripped so that all 100 rows are returned."""
+    """Distances of every query to the last k (= 100 by default) rows of the whole data set.  `answer_tail(q_rows)`
+    answers against a data set made of exactly those k rows (ids 0..k-1 = rows n-k..n-1); the
+    queries' predicates are stripped so that all k rows are returned."""
     q = np.array(queries, np.float32, copy=True)
     q[:, 0] = 0.0
     q[:, 1:4] = -1.0
     ids, dists = answer_tail(q)
     out = np.empty(dists.shape, np.float32)
-    # row n-1-s is tail row 99-s
-    np.put_along_axis(out, (99 - ids.astype(np.int64)), dists, axis=1)
+    # row n-1-s is tail row k-1-s
+    np.put_along_axis(out, (ids.shape[1] - 1 - ids.astype(np.int64)), dists, axis=1)
     return out
 
 
@@ -128,8 +129,8 @@ def run_data_sharded(answer_shard, row0, n_total, queries, pad_dists, group=None
     dist.all_gather_into_tensor(r0_all, r0_t, group=group)
     if engine is not None:
         pad_t = torch.from_numpy(np.ascontiguousarray(pad_dists, np.float32)).to(device)
-        out_i = torch.empty((nq, 100), dtype=torch.int32, device=device)
-        out_d = torch.empty((nq, 100), dtype=torch.float32, device=device)
+        out_i = torch.empty((nq, ids_t.shape[1]), dtype=torch.int32, device=device)
+        out_d = torch.empty((nq, ids_t.shape[1]), dtype=torch.float32, device=device)
         torch.cuda.synchronize()
         engine.merge_shards_device(ids_all.data_ptr(), d_all.data_ptr(), [int(r) for r in r0_all.cpu()], nq, n_total,
                                    pad_t.data_ptr(), out_i.data_ptr(), out_d.data_ptr())

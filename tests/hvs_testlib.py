@@ -77,6 +77,9 @@ def oracle():
     lib.hvs_oracle_gen_data.argtypes = [_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32]
     lib.hvs_oracle_gen_queries.restype = None
     lib.hvs_oracle_gen_queries.argtypes = [_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_int]
+    lib.hvs_oracle_set_k.restype = C.c_int
+    lib.hvs_oracle_set_k.argtypes = [C.c_int]
+    lib.hvs_oracle_get_k.restype = C.c_int
     _oracle = lib
     return lib
 
@@ -94,15 +97,32 @@ def oracle_dist(dvec, qvec, order="simd"):
     return np.float32(fn(_fp(d), _fp(q)))
 
 
+class oracle_k:
+    """`with oracle_k(k):` -- the oracle's k (the reference's compile-time KNN_LIMIT) for the calls inside."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.old = oracle().hvs_oracle_get_k()
+        assert oracle().hvs_oracle_set_k(self.k) == 0, "k outside 8..256"
+        return self
+
+    def __exit__(self, *a):
+        oracle().hvs_oracle_set_k(self.old)
+
+
 def oracle_query(nodes, queries, sample_proportion=1.0, engine="canonical", threads=8, part_threads=1,
                  hw_threads=8, run_parallel=False):
-    """Returns (ids[nq,100] u32, dists[nq,100] f32).  engine: canonical | knn | baseline."""
+    """Returns (ids[nq,k] u32, dists[nq,k] f32), k = 100 unless inside `with oracle_k(k)`.
+    engine: canonical | knn | baseline."""
     nodes, queries = _c(nodes, np.float32), _c(queries, np.float32)
     n, nq = nodes.shape[0], queries.shape[0]
     assert nodes.shape[1] == DCOLS and queries.shape[1] == QCOLS
-    ids = np.zeros((nq, K), np.uint32)
-    dists = np.zeros((nq, K), np.float32)
     lib = oracle()
+    k = lib.hvs_oracle_get_k()
+    ids = np.zeros((nq, k), np.uint32)
+    dists = np.zeros((nq, k), np.float32)
     if engine == "canonical":
         rc = lib.hvs_oracle_vec_query(_fp(nodes), n, _fp(queries), nq, sample_proportion, _up(ids), _fp(dists),
                                       threads)
@@ -121,6 +141,7 @@ def oracle_query(nodes, queries, sample_proportion=1.0, engine="canonical", thre
 
 def oracle_dists_for_ids(nodes, queries, ids, order="simd"):
     nodes, queries, ids = _c(nodes, np.float32), _c(queries, np.float32), _c(ids, np.uint32)
+    assert ids.shape[1] == oracle().hvs_oracle_get_k(), "ids rows do not hold the oracle's k entries (use oracle_k)"
     out = np.zeros(ids.shape, np.float32)
     fn = oracle().hvs_oracle_dists_for_ids if order == "simd" else oracle().hvs_oracle_dist_file_values
     fn(_fp(nodes), _fp(queries), queries.shape[0], _up(ids), _fp(out))
@@ -270,6 +291,7 @@ def check_parity(nodes, queries, got_ids, ref_ids, sample_proportion=1.0, got_di
     """
     nodes, queries = _c(nodes, np.float32), _c(queries, np.float32)
     got_ids, ref_ids = _c(got_ids, np.uint32), _c(ref_ids, np.uint32)
+    K = oracle().hvs_oracle_get_k()                      # 100 unless inside `with oracle_k(k)`
     assert got_ids.shape == ref_ids.shape == (queries.shape[0], K), (got_ids.shape, ref_ids.shape)
     n = nodes.shape[0]
     assert got_ids.max(initial=0) < n, "id out of range"

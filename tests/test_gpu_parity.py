@@ -12,7 +12,8 @@ import hvs_testlib as T
 
 pytestmark = pytest.mark.gpu
 PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
-GOLDENS = sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "*.npz")))
+KGOLDENS = sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "k*.npz")))                  # k != 100 (make_goldens_k.py)
+GOLDENS = [g for g in sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "*.npz"))) if g not in KGOLDENS]
 
 
 FILTER_ENGINES = [PKG.ENGINE_MFMA_FILTER, PKG.ENGINE_MFMA_I8]
@@ -703,3 +704,66 @@ def test_d1e8_config4_hbm_sizing():
     assert np.array_equal(T.oracle_dists_for_ids(nodes, queries[pick], ids[pick]).view(np.uint32), dists[pick].view(np.uint32))
     ref, _ = T.oracle_query(nodes, queries[pick], threads=16)
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
+
+
+@pytest.mark.parametrize("engine", [PKG.ENGINE_EXACT_SCAN, PKG.ENGINE_MFMA_FILTER, PKG.ENGINE_MFMA_I8], ids=["exact"] + FILTER_IDS)
+@pytest.mark.parametrize("path", KGOLDENS, ids=[os.path.basename(p)[:-4] for p in KGOLDENS])
+def test_other_k_matches_reference_built_with_that_k(path, engine):
+    """hvs_set_k: k = 8, 10 and 256 against output.bin of the reference compiled with that KNN_LIMIT
+    (include/optimized_impl.h:26), serial and threaded engine, and against the oracle with the same k."""
+    z = np.load(path)
+    nodes, queries = _inputs(z)
+    k = int(z["k"])
+    with PKG.Engine(0) as e:
+        e.set_engine(engine)
+        e.set_k(k)
+        assert e.k == k
+        e.load_data(nodes)
+        ids, dists = e.query(queries, 1.0)
+        t = e.last_timing()
+        assert ids.shape == (queries.shape[0], k) and t.engine == engine
+    with T.oracle_k(k):
+        T.check_parity(nodes, queries, ids, z["ids_optimized"], got_dists=dists)
+        T.check_parity(nodes, queries, ids, z["ids_optimized_parallel"])
+        ref, refd = T.oracle_query(nodes, queries)
+        assert np.array_equal(ids, ref) and np.array_equal(dists.view(np.uint32), refd.view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [8, 37, 128, 129, 200, 256])
+def test_k_sweep_all_engines_agree_with_the_oracle(k):
+    """k on both sides of the 128-key list boundary, ragged (37, 129, 200): the filter engines (levels, re-scoring,
+    merges) and the exact engine must return the oracle's bits; changing k on a live context drops old results and
+    keeps the data; n < k is refused."""
+    n, nq = 90_000, 260
+    nodes = T.gen_data(n, 600 + k, T.GEN_V1, 60)
+    queries = T.gen_queries(nq, 700 + k, T.GEN_V1, 60)
+    queries[0, :4] = [3, 7, 0.5, 0.5003]      # a handful of rows: mostly padding
+    queries[1, :4] = [1, 999, -1, -1]         # no row at all: k pad rows
+    with T.oracle_k(k):
+        ref, refd = T.oracle_query(nodes, queries)
+        ref_half, refd_half = T.oracle_query(nodes, queries[:64], 0.5)
+    with PKG.Engine(0) as e:
+        e.load_data(nodes)                     # loaded at the default k = 100 ...
+        ids100, _ = e.query(queries[:8], 1.0)
+        assert ids100.shape == (8, 100)
+        e.set_k(k)                             # ... then k changes under it
+        for engine in (PKG.ENGINE_AUTO, PKG.ENGINE_MFMA_FILTER, PKG.ENGINE_EXACT_SCAN):
+            e.set_engine(engine)
+            ids, d = e.query(queries, 1.0)
+            assert e.last_timing().fallback_queries == 0
+            assert np.array_equal(ids, ref) and np.array_equal(d.view(np.uint32), refd.view(np.uint32)), (k, engine)
+            ids, d = e.query(queries[:64], 0.5)
+            assert np.array_equal(ids, ref_half) and np.array_equal(d.view(np.uint32), refd_half.view(np.uint32)), (k, engine)
+        with pytest.raises(PKG.HvsError):
+            e.set_k(7)
+        with pytest.raises(PKG.HvsError):
+            e.set_k(257)
+    with PKG.Engine(0) as e:
+        e.set_k(256)
+        with pytest.raises(PKG.HvsError):
+            e.load_data(T.gen_data(255))       # n < k: the reference's padding index would underflow
+    with PKG.Engine(devices=[0, 0]) as m:      # multi-GPU context: k reaches every part
+        m.set_k(k)
+        m.load_data(nodes)
+        ids, d = m.query(queries, 1.0)
+        assert np.array_equal(ids, ref) and np.array_equal(d.view(np.uint32), refd.view(np.uint32))

@@ -9,7 +9,9 @@ import pytest
 
 import hvs_testlib as T
 
-GOLDENS = sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "*.npz")))
+ALL = sorted(glob.glob(os.path.join(T.GOLDEN_DIR, "*.npz")))
+KGOLDENS = [g for g in ALL if os.path.basename(g).startswith("k")]     # k != 100 (tests/golden/make_goldens_k.py)
+GOLDENS = [g for g in ALL if g not in KGOLDENS]
 SMALL = [g for g in GOLDENS if "d1m" not in g]
 
 
@@ -82,6 +84,28 @@ def test_oracle_matches_reference_outputs(path):
         if "ids_" + eng in z:
             vals = T.oracle_dists_for_ids(nodes, queries, z["ids_" + eng], order="scalar")
             assert np.array_equal(vals.view(np.uint32), z["distfile_" + eng].view(np.uint32))
+
+
+@pytest.mark.parametrize("path", KGOLDENS, ids=[os.path.basename(p)[:-4] for p in KGOLDENS])
+def test_oracle_matches_reference_built_with_another_k(path):
+    """k != 100: the reference compiled with KNN_LIMIT = 8 / 10 / 256 (optimized_impl.h:26) wrote these
+    ids; the oracle with the same k must agree -- canonical engine up to ties, the faithful Knn emulation (find_worst
+    steps over K - K%8 slots + the overlapping last 8, optimized_impl.h:212-233) as id sets, serial and threaded."""
+    z, nodes, queries = load(path)
+    k = int(z["k"])
+    with T.oracle_k(k):
+        can_ids, can_d = T.oracle_query(nodes, queries, engine="canonical")
+        assert can_ids.shape == (queries.shape[0], k)
+        st = T.check_parity(nodes, queries, can_ids, z["ids_optimized"], got_dists=can_d)
+        assert st["identical"] + st["tie_permuted"] == st["queries"]
+        T.check_parity(nodes, queries, can_ids, z["ids_optimized_parallel"])
+        knn_ids, _ = T.oracle_query(nodes, queries, engine="knn", part_threads=1)
+        assert np.array_equal(np.sort(knn_ids, axis=1), np.sort(z["ids_optimized"], axis=1))
+        par_ids, _ = T.oracle_query(nodes, queries, engine="knn", part_threads=0, hw_threads=8)
+        assert np.array_equal(np.sort(par_ids, axis=1), np.sort(z["ids_optimized_parallel"], axis=1))
+        if k > 100:   # types 1/3 match fewer than k rows here: padding with duplicates (optimized_parallel.hpp:149-157)
+            assert sum(len(set(r.tolist())) < k for r in z["ids_optimized"]) > 0
+    assert T.oracle().hvs_oracle_get_k() == 100
 
 
 def test_oracle_matches_reference_1m_slice():
