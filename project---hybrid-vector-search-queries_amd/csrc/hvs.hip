@@ -80,6 +80,12 @@ struct hvs_ctx {
     HvsBatch fb{};
     uint32_t fb_slots_cap = 0;
     uint32_t* d_layout = nullptr;
+    // work-item lists of the current batch (HvsItems): per-quad block ranges, per-segment counts / offsets, the list
+    uint32_t *d_qlo = nullptr, *d_qhi = nullptr, *d_segcnt = nullptr, *d_segoff = nullptr, *d_lvloff = nullptr, *d_cursor = nullptr;
+    uint32_t* d_items = nullptr;
+    size_t items_cap = 0;
+    uint32_t quads_cap = 0, segs_cap = 0;
+    int num_cus = 256;
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
     uint32_t fallback_queries = 0;
     uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
@@ -692,13 +698,52 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     return HVS_OK;
 }
 
+// work-item lists of the batch just prepared (all levels at once; see HvsItems in hvs_filter.h)
+int build_items(hvs_ctx* c)
+{
+    const HvsBatch& B = c->fb;
+    const HvsLevels L = c->lv;
+    const HvsSegs S = hvs_make_segs(L);
+    const uint32_t nquads = hvs_ceil_div(B.ngroups, HVS_WG_WAVES), nseg = S.first[L.K + 1];
+    if (nquads > (1u << HVS_ITEM_QUAD_BITS)) return fail(c, HVS_EINVAL, "internal: too many query quads for the item code");
+    int rc;
+    if (nquads > c->quads_cap) {
+        if ((rc = dev_alloc(c, &c->d_qlo, (size_t)nquads))) return rc;
+        if ((rc = dev_alloc(c, &c->d_qhi, (size_t)nquads))) return rc;
+        c->quads_cap = nquads;
+    }
+    if (nseg + 1u > c->segs_cap) {
+        if ((rc = dev_alloc(c, &c->d_segcnt, (size_t)nseg + 1u))) return rc;
+        if ((rc = dev_alloc(c, &c->d_segoff, (size_t)nseg + 1u))) return rc;
+        c->segs_cap = nseg + 1u;
+    }
+    if (!c->d_lvloff && (rc = dev_alloc(c, &c->d_lvloff, (size_t)32))) return rc;
+    if (!c->d_cursor && (rc = dev_alloc(c, &c->d_cursor, (size_t)16))) return rc;
+    const size_t worst = (size_t)nquads * (size_t)(nseg - S.first[1]);  // every quad meets every segment (type 0)
+    if (worst > c->items_cap) {
+        if ((rc = dev_alloc(c, &c->d_items, worst))) return rc;
+        c->items_cap = worst;
+    }
+    HVS_HIP(c, hipMemsetAsync(c->d_cursor, 0, 16 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(hvs_k_quad_ranges, dim3(hvs_ceil_div(nquads, 256u)), dim3(256), 0, c->stream, B, nquads, c->d_qlo, c->d_qhi);
+    hipLaunchKernelGGL(hvs_k_item_sweep<false>, dim3(nseg), dim3(256), 0, c->stream, L, S, nquads, c->d_qlo, c->d_qhi, c->d_segcnt,
+                       c->d_segoff, c->d_items);
+    hipLaunchKernelGGL(hvs_k_item_scan, dim3(1), dim3(1024), 0, c->stream, S, c->d_segcnt, c->d_segoff, c->d_lvloff);
+    hipLaunchKernelGGL(hvs_k_item_sweep<true>, dim3(nseg), dim3(256), 0, c->stream, L, S, nquads, c->d_qlo, c->d_qhi, c->d_segcnt,
+                       c->d_segoff, c->d_items);
+    HVS_HIP(c, hipGetLastError());
+    return HVS_OK;
+}
+
 int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 {
     const int fmt = c->tile_fmt;
     int rc = prep_batch(c, q0, nqb, sn == c->n, fmt);
     if (rc) return rc;
+    if (fmt == HVS_FMT_I8X16 && (rc = build_items(c))) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
+    const HvsItems W{c->d_items, c->d_lvloff, c->d_cursor};
     const uint32_t n = c->n;
     if (sn != n)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
@@ -740,9 +785,10 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
             const uint32_t count = L.off[level + 1] - L.off[level];
             const int ev = kernel_timer_begin(c);
             const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
-            if (fmt == HVS_FMT_I8X16)
-                hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,
-                                   c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
+            if (fmt == HVS_FMT_I8X16)  // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
+                hipLaunchKernelGGL(hvs_k_filter_i8x16, dim3(4u * (uint32_t)c->num_cus), dim3(64 * HVS_WG_WAVES), 0, c->stream,
+                                   c->d_tiles_ct, c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W,
+                                   c->d_counters);
             else if (fmt == HVS_FMT_I8)
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_I8>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
                                    c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
@@ -893,6 +939,10 @@ int leaf_create(hvs_ctx** out, int device)
         return HVS_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+    }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -930,7 +980,8 @@ void leaf_destroy(hvs_ctx* c)
         HvsBatch& B = c->fb;
         void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
                       B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
-                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count};
+                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count,
+                      c->d_qlo, c->d_qhi, c->d_segcnt, c->d_segoff, c->d_lvloff, c->d_cursor, c->d_items};
         for (void* p : fp)
             if (p) (void)hipFree(p);
     }

@@ -77,6 +77,29 @@ static float exact_dist(const float* d, const float* q)
     return a + b2;
 }
 
+// What the reference's checker reports about two .dist files (src/compare_data.cpp:5-78): whether all distances
+// agree exactly, agree within the absolute tolerance, or how many do not.  The verdict lines are the CLI contract
+// (run.sh greps nothing, people read them); the bookkeeping behind them is this file's own.
+struct DistVerdict {
+    double worst = 0.0;               // largest |a - b|
+    uint64_t beyond = 0;              // entries with |a - b| >= error_delta
+    std::vector<size_t> examples;     // the first few of them (flat index)
+};
+
+static DistVerdict judge_dists(const std::vector<float>& a, const std::vector<float>& b)
+{
+    DistVerdict v;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const double gap = std::fabs((double)a[i] - (double)b[i]);
+        v.worst = std::max(v.worst, gap);
+        if (gap >= error_delta) {
+            if (v.examples.size() < 49) v.examples.push_back(i);
+            ++v.beyond;
+        }
+    }
+    return v;
+}
+
 static void compare_dist(const std::string& a_path, const std::string& b_path)
 {
     std::cout << "\nComparing: " << a_path << " " << b_path << std::endl;
@@ -86,30 +109,24 @@ static void compare_dist(const std::string& a_path, const std::string& b_path)
         std::cerr << "cannot read " << a_path << " / " << b_path << std::endl;
         return;
     }
-    if (na != nb) {
+    if (na != nb || a.size() != b.size()) {
         std::cerr << "Datasets have different number of queries! " << na << ", " << nb << std::endl;
         return;
     }
-    bool success = true, same = true;
-    uint32_t errs = 0;
-    double max_error = 0;
-    for (size_t i = 0; i < a.size(); ++i) {
-        const double diff = std::abs((double)a[i] - (double)b[i]);
-        if (diff > max_error) { max_error = diff; same = false; }
-        if (diff >= error_delta) {
-            success = false;
-            if (++errs < 50)
-                std::cerr << i / 100 << " - " << i % 100 << ": distance difference of " << diff << " between "
-                          << std::setprecision(15) << a[i] << " and " << b[i] << std::endl;
-        }
-    }
-    if (success && same) {
+    const size_t per_query = na ? a.size() / na : 1;  // k of the files (100 unless written with another k)
+    const DistVerdict v = judge_dists(a, b);
+    for (size_t i : v.examples)
+        std::cerr << i / per_query << " - " << i % per_query << ": distance difference of " << std::fabs((double)a[i] - (double)b[i])
+                  << " between " << std::setprecision(15) << a[i] << " and " << b[i] << std::endl;
+    if (v.worst == 0.0) {
         std::cout << "Datasets are the same!" << std::endl;
-    } else {
-        if (success) std::cout << "Datasets are similar under error delta!" << std::endl;
-        else std::cout << "ERROR: Found a total of " << errs << " differences!" << std::endl;
-        std::cout << "Max Floating Point Error Difference: " << std::setprecision(15) << max_error << std::endl;
+        return;
     }
+    if (v.beyond == 0)
+        std::cout << "Datasets are similar under error delta!" << std::endl;
+    else
+        std::cout << "ERROR: Found a total of " << v.beyond << " differences!" << std::endl;
+    std::cout << "Max Floating Point Error Difference: " << std::setprecision(15) << v.worst << std::endl;
 }
 
 // returns number of queries violating the tie-aware rule

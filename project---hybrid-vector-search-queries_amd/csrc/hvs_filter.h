@@ -1603,10 +1603,142 @@ __device__ __forceinline__ uint32_t hvs_hit_mask8(const hvs_i32x4& a0, const hvs
     return m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work-item lists of a batch (see HvsItems).  Segments of all levels are numbered consecutively (HvsSegs); per quad
+// of groups the union block range and ordering; per (level, segment) the quads whose range meets it.
+//   hvs_k_quad_ranges : per quad [block lo, block hi) over its groups (those that share the first group's ordering)
+//   hvs_k_item_count  : one workgroup per (level, segment): how many quads cover it
+//   hvs_k_item_scan   : exclusive prefix over all segments (one workgroup) + per-level offsets
+//   hvs_k_item_fill   : the same sweep as the count, writing (segment << 12 | quad) in quad order
+// ---------------------------------------------------------------------------------------------
+#define HVS_ITEM_QUAD_BITS 12  // item code: (segment within the level << 12) | quad of groups
+struct HvsSegs {
+    uint32_t first[17];  // first global segment number of each level; first[K + 1] = total
+    uint32_t K;
+};
+static inline HvsSegs hvs_make_segs(const HvsLevels& L)
+{
+    HvsSegs S{};
+    S.K = L.K;
+    uint32_t t = 0;
+    for (uint32_t j = 0; j <= L.K; ++j) {
+        S.first[j] = t;
+        t += hvs_ceil_div(L.off[j + 1] - L.off[j], HVS_SEG);
+    }
+    for (uint32_t j = L.K + 1; j < 17u; ++j) S.first[j] = t;
+    return S;
+}
+
+__global__ void hvs_k_quad_ranges(HvsBatch B, uint32_t nquads, uint32_t* __restrict__ qlo, uint32_t* __restrict__ qhi)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nquads) return;
+    const uint32_t g0 = q * HVS_WG_WAVES, ord = B.gord[g0];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t w = 0; w < HVS_WG_WAVES; ++w) {
+        const uint32_t g = g0 + w;
+        if (g >= B.ngroups || B.gord[g] != ord || B.gub[g] <= B.gua[g]) continue;
+        const uint32_t a = B.gua[g] / 32u, b = hvs_ceil_div(B.gub[g], 32u);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    qlo[q] = lo < hi ? lo : 0u;
+    qhi[q] = lo < hi ? hi : 0u;
+}
+
+// does quad range [blo, bhi) (blocks) meet segment `seg` of `level`?
+__device__ __forceinline__ bool hvs_quad_meets(const HvsLevels& L, uint32_t level, uint32_t seg, uint32_t blo, uint32_t bhi)
+{
+    if (bhi <= blo) return false;
+    uint32_t lo, hi;
+    hvs_level_run(L, level, blo, bhi, lo, hi);
+    const uint32_t seg_lo = L.off[level] + seg * HVS_SEG;
+    return seg_lo < hi && seg_lo + HVS_SEG > lo;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void hvs_k_item_sweep(HvsLevels L, HvsSegs S, uint32_t nquads, const uint32_t* __restrict__ qlo,
+                                                        const uint32_t* __restrict__ qhi, uint32_t* __restrict__ segcnt,
+                                                        const uint32_t* __restrict__ segoff, uint32_t* __restrict__ list)
+{
+    __shared__ uint32_t swave[4];
+    __shared__ uint32_t sbase;
+    const uint32_t gs = blockIdx.x;  // global segment number
+    uint32_t level = 1;              // (level 0 is the exact seed's: no filter launch)
+    while (level < S.K && gs >= S.first[level + 1]) ++level;
+    if (gs < S.first[1]) return;
+    const uint32_t seg = gs - S.first[level];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0u) sbase = FILL ? segoff[gs] : 0u;
+    __syncthreads();
+    for (uint32_t q0 = 0; q0 < nquads; q0 += 256u) {
+        const uint32_t q = q0 + threadIdx.x;
+        const bool hit = q < nquads && hvs_quad_meets(L, level, seg, qlo[q], qhi[q]);
+        const uint64_t m = __ballot(hit);
+        if (lane == 0u) swave[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            before += w < wv ? swave[w] : 0u;
+            total += swave[w];
+        }
+        if (FILL && hit) list[sbase + before + hvs_prefix_count(m)] = (seg << HVS_ITEM_QUAD_BITS) | q;
+        __syncthreads();
+        if (threadIdx.x == 0u) sbase += total;
+        __syncthreads();
+    }
+    if (!FILL && threadIdx.x == 0u) segcnt[gs] = sbase;
+}
+
+// exclusive prefix of segcnt[0 .. nseg) -> segoff[0 .. nseg]; lvloff[j] = segoff[S.first[j]].  One workgroup of 1024.
+__global__ __launch_bounds__(1024) void hvs_k_item_scan(HvsSegs S, const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff,
+                                                        uint32_t* __restrict__ lvloff)
+{
+    __shared__ uint32_t spart[1024];
+    const uint32_t nseg = S.first[S.K + 1];
+    const uint32_t per = hvs_ceil_div(nseg, 1024u);
+    const uint32_t a = threadIdx.x * per, b = (a + per) < nseg ? (a + per) : nseg;
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += (i >= S.first[1]) ? segcnt[i] : 0u;
+    spart[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {  // inclusive scan of the per-thread sums
+        const uint32_t v = threadIdx.x >= o ? spart[threadIdx.x - o] : 0u;
+        __syncthreads();
+        spart[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? spart[threadIdx.x - 1u] : 0u;
+    for (uint32_t i = a; i < b; ++i) {
+        segoff[i] = run;
+        run += (i >= S.first[1]) ? segcnt[i] : 0u;
+    }
+    if (threadIdx.x == 1023u) segoff[nseg] = spart[1023];
+    __syncthreads();
+    if (threadIdx.x <= S.K + 1u) lvloff[threadIdx.x] = threadIdx.x == S.K + 1u ? spart[1023] : 0u;
+    __syncthreads();
+    // (segoff is complete only after every thread's loop: read it back through global memory after a fence)
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x <= S.K) lvloff[threadIdx.x] = segoff[S.first[threadIdx.x]];
+}
+
+// Work items.  A launch of one level is a fixed number of workgroups that pull (quad of groups, segment) items from
+// the level's list (HvsItems, built per batch by hvs_k_item_*: only pairs whose ranges meet, ordered segment-major so
+// that concurrent workgroups stream the same tiles) with one atomic per item.  A 2-D grid over all (quad, segment)
+// pairs is mostly empty for windowed predicates -- 75 % of the workgroups of a 25 % timestamp window, > 98 % for
+// categorical ones -- and the empties cost ~7 ns each of dispatch time (18 % of a type-2 batch's filter time).
+struct HvsItems {
+    const uint32_t* list;    // items of all levels: (segment within the level << 12) | quad
+    const uint32_t* lvloff;  // [K + 2] first item of each level; lvloff[level + 1] - lvloff[level] = the level's items
+    uint32_t* cursor;        // [16] next item of each level (zeroed per batch)
+};
+
 __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_i8x16(
     const uint4* __restrict__ tiles_ct, const uint4* __restrict__ tiles_t, const uint4* __restrict__ nrm_ct,
     const uint4* __restrict__ nrm_t, const uint32_t* __restrict__ bpos_ct, const uint32_t* __restrict__ bpos_t, HvsLevels L,
-    uint32_t level, HvsBatch B, unsigned long long* __restrict__ counters)
+    uint32_t level, HvsBatch B, HvsItems W, unsigned long long* __restrict__ counters)
 {
     constexpr int STG = HVS_STAGE_I8;
     constexpr int TILE_U4 = HVS_I8X16_TILE_U4;
@@ -1618,15 +1750,24 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     __shared__ uint4 snrm[2][STG * NRM_U4];    // 2 x 1 KiB
     __shared__ uint64_t sbuf[HVS_WG_WAVES][256];
     __shared__ uint32_t srange[HVS_WG_WAVES][2];
+    __shared__ uint32_t sitem;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t g = blockIdx.x * HVS_WG_WAVES + wv;
-    const uint32_t gq = blockIdx.x * HVS_WG_WAVES;
+    const uint32_t item0 = W.lvloff[level], nitems = W.lvloff[level + 1u] - item0;
+  for (;;) {  // one work item per turn; every workgroup leaves when the level's list is exhausted
+    if (threadIdx.x == 0u) sitem = atomicAdd(&W.cursor[level], 1u);
+    __syncthreads();
+    const uint32_t item = __builtin_amdgcn_readfirstlane(sitem);
+    if (item >= nitems) break;  // uniform over the workgroup
+    const uint32_t code = __builtin_amdgcn_readfirstlane(W.list[item0 + item]);
+    const uint32_t quad = code & ((1u << HVS_ITEM_QUAD_BITS) - 1u), segment = code >> HVS_ITEM_QUAD_BITS;
+    const uint32_t g = quad * HVS_WG_WAVES + wv;
+    const uint32_t gq = quad * HVS_WG_WAVES;
     const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
     const uint4* __restrict__ nrm = ord ? nrm_t : nrm_ct;
-    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
+    const uint32_t seg_lo = L.off[level] + segment * HVS_SEG;
     uint32_t i0 = 0, i1 = 0;
     if (g < B.ngroups && B.gord[g] == ord) {
         uint32_t lo, hi;
@@ -1647,7 +1788,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         I0 = srange[w][0] < I0 ? srange[w][0] : I0;
         I1 = srange[w][1] > I1 ? srange[w][1] : I1;
     }
-    if (I0 >= I1) return;  // uniform over the workgroup
+    if (I0 >= I1) continue;  // uniform over the workgroup (cannot happen with a well-formed list)
     I0 = __builtin_amdgcn_readfirstlane(I0);
     I1 = __builtin_amdgcn_readfirstlane(I1);
     i0 = __builtin_amdgcn_readfirstlane(i0);
@@ -1845,6 +1986,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         flush();
         if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
     }
+  }  // next work item (the last stage barrier has released the stage buffers)
 }
 
 // ---------------------------------------------------------------------------------------------
