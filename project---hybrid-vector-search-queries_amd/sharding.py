@@ -35,6 +35,28 @@ def gather_ids(local_ids, nq: int, group=None):
     return torch.cat(parts, 0)
 
 
+def gather_ids_to_root(local_ids, nq: int, dst: int = 0, group=None):
+    """The result gather of the multi-GPU plan: every rank's [q0,q1) x k block of ids travels to rank
+    `dst` only (RCCL gather over xGMI on GPUs: rank 0 alone writes output.bin, so the other ranks need nothing --
+    an all_gather would move world x the bytes).  Returns the nq x k array on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = -(-nq // world)  # ranks pad to the largest shard so that one fixed-size gather suffices
+    pad = torch.zeros((per, local_ids.shape[1]), dtype=local_ids.dtype, device=local_ids.device)
+    pad[: local_ids.shape[0]] = local_ids
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        q0, q1 = shard_range(nq, r, world)
+        parts.append(bufs[r][: q1 - q0])
+    return torch.cat(parts, 0)
+
+
 def run_sharded(answer, queries: np.ndarray, group=None, device="cpu"):
     """answer(q_rows) -> (n_local x 100) uint32 ids for this rank's queries.  Returns all ids."""
     import torch

@@ -28,6 +28,24 @@ if sq:
     names = sorted({r["Counter_Name"] for r in sq})
     per = {n: per_dispatch(sq, n) for n in names}
     res["sq_per_filter_launch"] = per
+    # per launch (= per index level, in launch order): how busy the matrix pipes were and where the waves waited.
+    # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs; the SQ_WAIT_* /
+    # SQ_ACTIVE_* / SQ_WAVE_CYCLES counters share one unit, so their ratios are unit-free.
+    try:
+        lv = []
+        for i in range(len(per["SQ_WAVE_CYCLES"])):
+            g = per["GRBM_GUI_ACTIVE"][i] / 8.0
+            lv.append({"launch": i, "xcd_cycles": g,
+                       "simd_mfma_busy_frac": per["SQ_VALU_MFMA_BUSY_CYCLES"][i] / (g * 1024.0) if g else None,
+                       "wait_any": per["SQ_WAIT_ANY"][i] / per["SQ_WAVE_CYCLES"][i],
+                       "wait_inst": per["SQ_WAIT_INST_ANY"][i] / per["SQ_WAVE_CYCLES"][i],
+                       "active": per["SQ_ACTIVE_INST_ANY"][i] / per["SQ_WAVE_CYCLES"][i],
+                       "valu_insts": per["SQ_INSTS_VALU"][i], "salu_insts": per["SQ_INSTS_SALU"][i]})
+        json.dump({"what": "filter kernel, one launch per index level, in launch order; simd_mfma_busy_frac = "
+                           "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)", "levels": lv},
+                  open(outdir + "/sq_counters_filter_per_level.json", "w"), indent=1)
+    except Exception as e:
+        res["per_level_error"] = str(e)
     try:
         last = {n: v[-1] for n, v in per.items()}
         res["last_level"] = {"mfma_busy_frac_of_wave_cycles": last["SQ_VALU_MFMA_BUSY_CYCLES"] / last["GRBM_GUI_ACTIVE"] if "GRBM_GUI_ACTIVE" in last else None,

@@ -32,6 +32,14 @@ def _worker(rank, world, port, nq, out_dir):
     queries = T.gen_queries(nq, 12)
     ids = sharding.run_sharded(lambda q: T.oracle_query(nodes, q)[0], queries)
     np.save(os.path.join(out_dir, f"ids{rank}.npy"), ids)
+    # the gather bench.py runs on GPUs: blocks travel to rank 0 only
+    import torch
+    q0, q1 = sharding.shard_range(nq, rank, world)
+    mine = torch.from_numpy(np.ascontiguousarray(ids[q0:q1]).view(np.int32))
+    root = sharding.gather_ids_to_root(mine, nq, dst=0)
+    assert (root is None) == (rank != 0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "root.npy"), root.numpy().view(np.uint32))
     dist.destroy_process_group()
 
 
@@ -45,6 +53,7 @@ def test_two_rank_gloo_run_matches_single_process(tmp_path, nq):
     for r in range(2):
         got = np.load(tmp_path / f"ids{r}.npy")
         assert np.array_equal(got, want), f"rank {r} sees a different gathered result"
+    assert np.array_equal(np.load(tmp_path / "root.npy"), want), "gather to rank 0 differs"
 
 
 def _brute_partial(nodes, queries, row0, row1):
