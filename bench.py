@@ -99,13 +99,19 @@ def main():
     gathered = ([torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(world)]
                 if use_dist and rank == 0 else None)
 
+    gather_done = [None, None]                                         # event after the gather that last read each send buffer
+
     def step(b):
         eng.query_resident(b * a.batch, a.batch, 1.0)                  # asynchronous on the library's stream
         if use_dist:
             buf = ids_dev[b & 1]
+            if gather_done[b & 1] is not None:
+                gather_done[b & 1].synchronize()                       # (two steps old: long done; keeps the buffer reuse honest)
             eng.export_results_device(b * a.batch, a.batch, buf.data_ptr())
             eng.sync()                                                 # the block is complete (one host wait per step)
             dist.gather(buf, gathered, dst=0)                          # RCCL, asynchronous on torch's stream
+            gather_done[b & 1] = torch.cuda.Event()
+            gather_done[b & 1].record()
         else:
             eng.sync()
 

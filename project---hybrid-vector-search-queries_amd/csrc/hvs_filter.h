@@ -43,7 +43,7 @@
 #define HVS_FCAP 1024         // per-query candidate keys per round
 #define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
 #ifndef HVS_SEG
-#define HVS_SEG 128           // row blocks per filter work item
+#define HVS_SEG 256           // row blocks per filter work item (128: -1 % mixed, -2.7 % type-0: twice the item prologues)
 #endif
 #ifndef HVS_STAGE
 #define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage), BF16 tiles (7 KiB)
@@ -1995,14 +1995,15 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // Front end (per wave, 64 survivor entries at a time, lane = entry): the k-th set bit of every entry's mask is
 // turned into a (slot, row position) pair, range-tested against the slot's own position range and packed into a
 // wave-private list in LDS; rounds repeat while any entry has bits left (usually one round).
-// Back end: EIGHT lanes per pair, lane j playing AVX lane j of the reference (optimized_impl.h:96-125):
-// it accumulates dims j, 8+j, ..., 88+j (and 92+j for j >= 4: the masked tail) in that order, then the
-// horizontal sum ((a0+a4)+(a1+a5))+((a2+a6)+(a3+a7)) runs across the 8 lanes (xor 4, xor 1, xor 2; f32
-// addition is commutative, so every lane ends with the same bits as the sequential hvs_exact_dist).
-// The point is the memory access: one load instruction of a wave reads 8 rows x 32 contiguous bytes, and the
+// Back end: FOUR lanes per pair, lane t playing AVX lanes 2t and 2t+1 of the reference (optimized_impl.h:96-125) as one
+// packed f32 pair: it accumulates dims 8b+2t, 8b+2t+1 for b = 0..11 (and 96..99 into accumulators 4..7: the masked
+// tail) in that order, then the horizontal sum ((a0+a4)+(a1+a5))+((a2+a6)+(a3+a7)) runs across the 4 lanes (xor 2,
+// x + y, xor 1; f32 addition is commutative, so lane 0 ends with the same bits as the sequential hvs_exact_dist).
+// The point is the memory access: one load instruction of a wave reads 16 rows x 32 contiguous bytes, and the
 // four instructions that walk one 128-byte line follow each other directly.  (One lane per pair -- 64 rows
 // x 8 bytes per instruction, each line revisited by 16 instructions spread over the whole row walk --
-// re-fetched lines from L2/HBM many times.)
+// re-fetched lines from L2/HBM many times; eight lanes per pair with scalar math, round 1's form, issued twice
+// the vector and load instructions per pair.)
 // ---------------------------------------------------------------------------------------------
 // E16: entries of the 16x16 tile format (hvs_entry16_*) instead of the 32x32 formats' (hvs_entry_*)
 template <bool E16>
@@ -2033,22 +2034,50 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     __syncthreads();
     const uint32_t* __restrict__ perm = B.gord[g] ? perm_t : perm_ct;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t j = lane & 7u;
     uint64_t* list = slist[w];
     uint32_t npairs = 0;  // wave-uniform
     auto emask = [](uint64_t e) -> uint32_t { return E16 ? hvs_entry16_mask(e) : hvs_entry_mask(e); };
     auto epos = [](uint64_t e, uint32_t r) -> uint32_t { return E16 ? hvs_entry16_pos(e, r) : hvs_entry_pos(e, r); };
 
-    // exact distances of list[0..cnt) = (slot << 32 | row id).  HVS_RESCORE_UNROLL groups of 8 pairs per pass: their
-    // row loads are all issued before the first use, so a wave keeps 32 rows in flight
-    auto score_list = [&](uint32_t cnt) {
-        for (uint32_t p0 = 0; p0 < cnt; p0 += 8u * HVS_RESCORE_UNROLL) {  // wave-uniform
-            uint32_t slot[HVS_RESCORE_UNROLL], id[HVS_RESCORE_UNROLL];
-            bool ok[HVS_RESCORE_UNROLL];
-            float dk[HVS_RESCORE_UNROLL][13];
+    // exact distances of list[0..cnt) = (slot << 32 | row id).  FOUR lanes per pair, lane t holding the reference's AVX
+    // accumulators (2t, 2t+1) as one packed f32 pair: per 8-wide step it loads dims 8b+2t, 8b+2t+1 of the row (one
+    // 8-byte load; a wave instruction still reads whole 32-byte row segments) and of the query (LDS), then v_pk_add
+    // (d - q), v_pk_mul, v_pk_add -- each element one IEEE operation, the same bits as the scalar form
+    // (optimized_impl.h:96-125).  The masked tail puts dims 96..99 into accumulators 4..7 = lanes 2 and 3.  hsum
+    // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) (optimized_impl.h:37-47): pair + pair of lane t^2, x + y, lane 0 + lane 1.
+    // Half the vector and load instructions per pair of the 8-lane form (the low levels, whose rows sit in L2, are
+    // instruction-bound).  HVS_RESCORE_UNROLL groups of 16 pairs per pass keep 32 rows in flight per wave.
+    constexpr int kUn = HVS_RESCORE_UNROLL / 2 > 0 ? HVS_RESCORE_UNROLL / 2 : 1;
+    const uint32_t t4 = lane & 3u;
+    // Accepted candidates take a place in their slot's list with a RETURNING atomic (~1-2 us).  Waiting for it inside
+    // the pass made every pass of 16-32 pairs cost one atomic round trip (the floor of the low levels, whose rows come
+    // from L2: 3.2 ms per level).  The key is therefore stored one pass later: the atomic travels under the next pass's
+    // row loads.  `retire` is called at the start of the next pass and once more at the end of the kernel.
+    uint32_t pend_k[kUn], pend_slot[kUn];
+    uint64_t pend_key[kUn];
+    bool pend[kUn];
     #pragma unroll
-            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                const uint32_t pi = p0 + 8u * u + (lane >> 3);
+    for (int u = 0; u < kUn; ++u) pend[u] = false;
+    auto retire = [&]() {
+    #pragma unroll
+        for (int u = 0; u < kUn; ++u) {
+            if (pend[u]) {
+                if (pend_k[u] < HVS_FCAP)
+                    B.cand[(size_t)pend_slot[u] * HVS_FCAP + pend_k[u]] = pend_key[u];
+                else
+                    B.overflow[pend_slot[u]] = 1u;
+            }
+            pend[u] = false;
+        }
+    };
+    auto score_list = [&](uint32_t cnt) {
+        for (uint32_t p0 = 0; p0 < cnt; p0 += 16u * kUn) {  // wave-uniform
+            uint32_t slot[kUn], id[kUn];
+            bool ok[kUn];
+            hvs_f2 dk[kUn][13];
+    #pragma unroll
+            for (int u = 0; u < kUn; ++u) {
+                const uint32_t pi = p0 + 16u * u + (lane >> 2);
                 const uint64_t pr = list[pi < cnt ? pi : 0u];
                 slot[u] = (uint32_t)(pr >> 32);
                 id[u] = (uint32_t)pr;
@@ -2056,38 +2085,37 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
                 ok[u] = pi < cnt && id[u] < sn;
             }
     #pragma unroll
-            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                const float* __restrict__ dv = D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2;
+            for (int u = 0; u < kUn; ++u) {
+                const hvs_f2* __restrict__ dv = reinterpret_cast<const hvs_f2*>(D + (size_t)(ok[u] ? id[u] : 0u) * HVS_DCOLS + 2);
     #pragma unroll
-                for (int b = 0; b < 12; ++b) dk[u][b] = dv[8 * b + j];
-                dk[u][12] = dv[92u + (j | 4u)];
+                for (int b = 0; b < 12; ++b) dk[u][b] = dv[4 * b + t4];
+                dk[u][12] = dv[46u + (t4 | 2u)];  // dims 96,97 (lanes 0, 2) / 98,99 (lanes 1, 3); used by lanes 2, 3
             }
+            retire();  // the previous pass's candidates: their atomics have long returned
     #pragma unroll
-            for (int u = 0; u < HVS_RESCORE_UNROLL; ++u) {
-                const float* qv = &sq[slot[u] - g * HVS_GROUP][0];
-                float acc = 0.0f;
+            for (int u = 0; u < kUn; ++u) {
+                const hvs_f2* qv = reinterpret_cast<const hvs_f2*>(&sq[slot[u] - g * HVS_GROUP][0]);
+                hvs_f2 acc = hvs_f2{0.0f, 0.0f};
     #pragma unroll
                 for (int b = 0; b < 12; ++b) {
-                    float t = dk[u][b] - qv[8 * b + j];
+                    hvs_f2 t = dk[u][b] - qv[4 * b + t4];
                     t = t * t;
                     acc = acc + t;
                 }
                 {
-                    float t = dk[u][12] - qv[92u + (j | 4u)];
+                    hvs_f2 t = dk[u][12] - qv[46u + (t4 | 2u)];
                     t = t * t;
-                    const float with_tail = acc + t;
-                    acc = j >= 4u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
+                    const hvs_f2 with_tail = acc + t;
+                    acc = t4 >= 2u ? with_tail : acc;  // the masked tail feeds accumulators 4..7 only
                 }
-                const float sm = acc + __shfl_xor(acc, 4);
-                const float am = sm + __shfl_xor(sm, 1);
-                const float dist = am + __shfl_xor(am, 2);
-                if (ok[u] && j == 0u && dist <= B.tau[slot[u]]) {
-                    const uint32_t k = atomicAdd(&B.candcnt[slot[u]], 1u);
-                    if (k < HVS_FCAP)
-                        B.cand[(size_t)slot[u] * HVS_FCAP + k] = hvs_make_key(dist, id[u]);
-                    else
-                        B.overflow[slot[u]] = 1u;
-                }
+                // lanes t and t^2 hold (a_2t, a_2t+1) and (a_2t+4, a_2t+5) resp. the other way round
+                const hvs_f2 sm = acc + hvs_f2{__shfl_xor(acc.x, 2), __shfl_xor(acc.y, 2)};
+                const float am = sm.x + sm.y;                 // lane 0: (a0+a4)+(a1+a5), lane 1: (a2+a6)+(a3+a7)
+                const float dist = am + __shfl_xor(am, 1);
+                pend[u] = ok[u] && t4 == 0u && dist <= B.tau[slot[u]];
+                pend_slot[u] = slot[u];
+                pend_key[u] = hvs_make_key(dist, id[u]);
+                if (pend[u]) pend_k[u] = atomicAdd(&B.candcnt[slot[u]], 1u);  // (result used by the next retire)
             }
         }
     };
@@ -2146,6 +2174,7 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
         }
         cur = nxt;
     }
+    retire();
     if (lane == 0u && npairs) atomicAdd(&counters[2], (unsigned long long)npairs);
 }
 

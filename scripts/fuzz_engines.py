@@ -35,20 +35,25 @@ def case(rng, i):
         queries[0, :4] = [2, -1, 0.7, 0.2]; queries[1, :4] = [3, 0, -np.inf, np.inf]; queries[2, 0] = 9
         queries[3, :4] = [2, -1, np.nan, 1]; queries[4, :4] = [1, -0.0, -1, -1]; queries[5, :4] = [3, 1, 0.3, 0.3]
     sp = float(rng.choice([1.0, 1.0, 1.0, 0.9, 0.5, 0.26, 0.1]))
+    k = int(rng.choice([100, 100, 100, 8, 17, 129, 256]))           # hvs_set_k: both list capacities
+    k = min(k, n)
+    if k < 8: k = 100
+    parts = int(rng.choice([1, 1, 1, 2, 3]))                         # multi-GPU context with virtual ranks on GPU 0
     res = []
     for engine in (1, 2, 3):
-        with PKG.Engine(0) as e:
-            e.set_engine(engine); e.load_data(nodes)
+        with (PKG.Engine(0) if parts == 1 else PKG.Engine(devices=[0] * parts)) as e:
+            e.set_engine(engine); e.set_k(k); e.load_data(nodes)
             ids, d = e.query(queries, sp); t = e.last_timing()
         res.append((ids, d, t.engine, t.fallback_queries))
     same = all(np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) for r in res[1:])
-    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} engines={res[0][2]},{res[1][2]},{res[2][2]} fallback={res[1][3]},{res[2][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
+    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} k={k} parts={parts} engines={res[0][2]},{res[1][2]},{res[2][2]} fallback={res[1][3]},{res[2][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
     if not same:
         bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1) | (res[0][0] != res[2][0]).any(axis=1))[0]
         print("  first bad queries:", bad[:10], queries[bad[:3], :4]); np.savez("gpurun_out/fuzz_fail.npz", nodes=nodes, queries=queries, sp=sp)
     if n <= 5000 and nq <= 129:   # small cases also against the oracle
-        ref, _ = T.oracle_query(nodes, queries, sp)
-        T.check_parity(nodes, queries, res[1][0], ref, sample_proportion=sp, got_dists=res[1][1])
+        with T.oracle_k(k):
+            ref, _ = T.oracle_query(nodes, queries, sp)
+            T.check_parity(nodes, queries, res[1][0], ref, sample_proportion=sp, got_dists=res[1][1])
     return same
 
 if __name__ == "__main__":
