@@ -399,9 +399,13 @@ int choose_format(hvs_ctx* c)
     const double band8 = 2.0 * (double)hb.n_d8 * (double)hb.e_d8;
     const double infl16 = std::exp(std::min(50.0, z * 2.0 * band16 / sigma));
     const double infl8 = std::exp(std::min(50.0, z * 2.0 * band8 / sigma));
-    // cost model in units of one INT8 filter launch (D = 1e7, 2^20 mixed queries, profiles/r01_int8): the BF16
-    // filter takes 1.53x as long, re-scoring 0.235x at inflation 1 and grows with the candidates
-    const double cost16 = 1.53 + 0.235 * infl16, cost8 = 1.0 + 0.235 * infl8;
+    // cost model in units of one INT8 filter launch: the BF16 filter takes kPlanBf16 times as long, re-scoring
+    // kPlanRescore times at inflation 1 and grows with the candidates.  Defaults = this round's measurement on
+    // D = 1e7, 2^20 mixed queries (profiles/r02_i8x16: 44.7 / 23.0 ms per filter launch, 6.9 ms re-scoring per level);
+    // HVS_PLAN_BF16_COST / HVS_PLAN_RESCORE_COST (in hundredths) override them for other chips or data shapes.
+    const double kPlanBf16 = env_u32("HVS_PLAN_BF16_COST", 194u, 100u, 1000u) / 100.0;
+    const double kPlanRescore = env_u32("HVS_PLAN_RESCORE_COST", 30u, 1u, 1000u) / 100.0;
+    const double cost16 = kPlanBf16 + kPlanRescore * infl16, cost8 = 1.0 + kPlanRescore * infl8;
     c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? kI8Fmt : HVS_FMT_BF16;
     if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "i8"
         if (!std::strcmp(f, "bf16")) c->planned_fmt = HVS_FMT_BF16;
