@@ -64,7 +64,8 @@
 #define HVS_RESCORE_WAVES 8    // waves per re-scoring block (they share the group's queries in LDS)
 #endif
 #ifndef HVS_RESCORE_UNROLL
-#define HVS_RESCORE_UNROLL 4   // groups of 8 pairs a re-scoring wave keeps in flight
+#define HVS_RESCORE_UNROLL 2   // re-scoring: rows in flight per wave = 8 x this (16: one group of 16 pairs per pass; 32 and 64
+                               // measured 0.6 % and 8 % slower on the bench: more registers, fewer waves)
 #endif
 
 typedef __bf16 hvs_bf16x8 __attribute__((ext_vector_type(8)));
