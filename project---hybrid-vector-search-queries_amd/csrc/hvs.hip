@@ -85,6 +85,7 @@ struct hvs_ctx {
     uint32_t* d_items = nullptr;
     size_t items_cap = 0;
     uint32_t quads_cap = 0, segs_cap = 0;
+    HvsSegs segs{};  // of the current batch
     int num_cus = 256;
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
     uint32_t fallback_queries = 0;
@@ -707,8 +708,10 @@ int build_items(hvs_ctx* c)
 {
     const HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
-    const HvsSegs S = hvs_make_segs(L);
-    const uint32_t nquads = hvs_ceil_div(B.ngroups, HVS_WG_WAVES), nseg = S.first[L.K + 1];
+    const uint32_t nquads = hvs_ceil_div(B.ngroups, HVS_WG_WAVES);
+    const HvsSegs S = hvs_make_segs(L, nquads, 2u * (uint32_t)c->num_cus);
+    c->segs = S;
+    const uint32_t nseg = S.first[L.K + 1];
     if (nquads > (1u << HVS_ITEM_QUAD_BITS)) return fail(c, HVS_EINVAL, "internal: too many query quads for the item code");
     int rc;
     if (nquads > c->quads_cap) {
@@ -747,7 +750,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     if (fmt == HVS_FMT_I8X16 && (rc = build_items(c))) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
-    const HvsItems W{c->d_items, c->d_lvloff, c->d_cursor};
+    HvsItems W{c->d_items, c->d_lvloff, c->d_cursor, HVS_SEG};
     const uint32_t n = c->n;
     if (sn != n)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
@@ -789,6 +792,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
             const uint32_t count = L.off[level + 1] - L.off[level];
             const int ev = kernel_timer_begin(c);
             const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
+            W.segsize = c->segs.seg[level];
             if (fmt == HVS_FMT_I8X16)  // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
                 hipLaunchKernelGGL(hvs_k_filter_i8x16, dim3(4u * (uint32_t)c->num_cus), dim3(64 * HVS_WG_WAVES), 0, c->stream,
                                    c->d_tiles_ct, c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W,

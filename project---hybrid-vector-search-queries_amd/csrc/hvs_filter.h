@@ -1615,18 +1615,30 @@ __device__ __forceinline__ uint32_t hvs_hit_mask8(const hvs_i32x4& a0, const hvs
 #define HVS_ITEM_QUAD_BITS 12  // item code: (segment within the level << 12) | quad of groups
 struct HvsSegs {
     uint32_t first[17];  // first global segment number of each level; first[K + 1] = total
+    uint32_t seg[17];    // row blocks per work item of each level (a power of two, 8 .. HVS_SEG)
     uint32_t K;
 };
-static inline HvsSegs hvs_make_segs(const HvsLevels& L)
+// Segment size per level: HVS_SEG blocks where the batch has enough quads to fill the chip, smaller (down to one LDS
+// stage of 8 tiles) for small batches, so that a level of T blocks still makes ~4 work items per workgroup slot:
+// with 10^4 queries (20 quads) a fixed 256-block segment left the lower levels of D = 10^6 with 20 items for 512 slots.
+static inline HvsSegs hvs_make_segs(const HvsLevels& L, uint32_t nquads, uint32_t wg_slots)
 {
     HvsSegs S{};
     S.K = L.K;
     uint32_t t = 0;
     for (uint32_t j = 0; j <= L.K; ++j) {
+        const uint64_t T = L.off[j + 1] - L.off[j];
+        uint64_t want = T * (uint64_t)(nquads ? nquads : 1u) / (4ull * (wg_slots ? wg_slots : 1u));
+        uint32_t seg = 8u;
+        while (seg < HVS_SEG && (uint64_t)seg * 2u <= want) seg *= 2u;
+        S.seg[j] = seg;
         S.first[j] = t;
-        t += hvs_ceil_div(L.off[j + 1] - L.off[j], HVS_SEG);
+        t += hvs_ceil_div((uint32_t)T, seg);
     }
-    for (uint32_t j = L.K + 1; j < 17u; ++j) S.first[j] = t;
+    for (uint32_t j = L.K + 1; j < 17u; ++j) {
+        S.first[j] = t;
+        S.seg[j] = HVS_SEG;
+    }
     return S;
 }
 
@@ -1648,13 +1660,14 @@ __global__ void hvs_k_quad_ranges(HvsBatch B, uint32_t nquads, uint32_t* __restr
 }
 
 // does quad range [blo, bhi) (blocks) meet segment `seg` of `level`?
-__device__ __forceinline__ bool hvs_quad_meets(const HvsLevels& L, uint32_t level, uint32_t seg, uint32_t blo, uint32_t bhi)
+__device__ __forceinline__ bool hvs_quad_meets(const HvsLevels& L, uint32_t level, uint32_t seg, uint32_t segsize, uint32_t blo,
+                                               uint32_t bhi)
 {
     if (bhi <= blo) return false;
     uint32_t lo, hi;
     hvs_level_run(L, level, blo, bhi, lo, hi);
-    const uint32_t seg_lo = L.off[level] + seg * HVS_SEG;
-    return seg_lo < hi && seg_lo + HVS_SEG > lo;
+    const uint32_t seg_lo = L.off[level] + seg * segsize;
+    return seg_lo < hi && seg_lo + segsize > lo;
 }
 
 template <bool FILL>
@@ -1674,7 +1687,7 @@ __global__ __launch_bounds__(256) void hvs_k_item_sweep(HvsLevels L, HvsSegs S, 
     __syncthreads();
     for (uint32_t q0 = 0; q0 < nquads; q0 += 256u) {
         const uint32_t q = q0 + threadIdx.x;
-        const bool hit = q < nquads && hvs_quad_meets(L, level, seg, qlo[q], qhi[q]);
+        const bool hit = q < nquads && hvs_quad_meets(L, level, seg, S.seg[level], qlo[q], qhi[q]);
         const uint64_t m = __ballot(hit);
         if (lane == 0u) swave[wv] = (uint32_t)__popcll(m);
         __syncthreads();
@@ -1734,6 +1747,7 @@ struct HvsItems {
     const uint32_t* list;    // items of all levels: (segment within the level << 12) | quad
     const uint32_t* lvloff;  // [K + 2] first item of each level; lvloff[level + 1] - lvloff[level] = the level's items
     uint32_t* cursor;        // [16] next item of each level (zeroed per batch)
+    uint32_t segsize;        // row blocks per item at the level being launched (HvsSegs::seg)
 };
 
 __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_i8x16(
@@ -1768,14 +1782,14 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
     const uint4* __restrict__ nrm = ord ? nrm_t : nrm_ct;
-    const uint32_t seg_lo = L.off[level] + segment * HVS_SEG;
+    const uint32_t seg_lo = L.off[level] + segment * W.segsize;
     uint32_t i0 = 0, i1 = 0;
     if (g < B.ngroups && B.gord[g] == ord) {
         uint32_t lo, hi;
         hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
-        if (seg_lo < hi && seg_lo + HVS_SEG > lo) {
+        if (seg_lo < hi && seg_lo + W.segsize > lo) {
             i0 = seg_lo > lo ? seg_lo : lo;
-            i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+            i1 = (seg_lo + W.segsize) < hi ? (seg_lo + W.segsize) : hi;
         }
     }
     if (lane == 0u) {
