@@ -1769,6 +1769,7 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
         });
         if (!rc) {
             hvs_ctx* k0 = c->kids[0];
+            (void)hipSetDevice(k0->device);  // the copies are enqueued on GPU 0's stream
             for (uint32_t r = 1; r < N && !rc; ++r) {
                 const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
                 hvs_ctx* k = c->kids[r];
@@ -1780,7 +1781,6 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
                     rc = fail(c, HVS_EHIP, "hvs_query: peer copy of a result block failed");
             }
             if (!rc) {
-                (void)hipSetDevice(k0->device);
                 if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * c->k * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
                     (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToHost,
                                                  k0->stream) != hipSuccess) ||
