@@ -122,7 +122,7 @@ def main():
 
     for b in range(a.warmup):
         step(b)
-    kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback = 0.0, 0, 0, 0, 0.0, 0, 0
+    kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback, untimed = 0.0, 0, 0, 0, 0.0, 0, 0, 0
     fence()
     t0 = time.perf_counter()
     for b in range(a.warmup, total_batches):
@@ -135,6 +135,7 @@ def main():
         query_ms += tm.query_ms
         rescored += tm.rescored_pairs
         fallback += tm.fallback_queries
+        untimed += tm.untimed_launches
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -158,6 +159,7 @@ def main():
         flops_alg = 200.0 * pairs                                      # 2*100 per passing pair
         k_s = kern_ms / 1e3
         peak = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
+        assert untimed == 0, "some launches of the dominant kernel were not timed: no roofline from this run"
         achieved = flops_alg / k_s / 1e12 if k_s > 0 else 0.0
         traffic = None
         tf = os.path.join(REPO, "profiles", "traffic.json")

@@ -55,7 +55,8 @@ typedef struct hvs_timing {
     uint32_t fallback_queries; /* queries re-run by the exact scan after a filter overflow          */
     uint64_t rescored_pairs;   /* MFMA engine: (query,row) pairs handed to the exact re-scoring kernel */
     uint32_t n_gpus;      /* GPUs that took part (multi-GPU context: query_ms = the slowest GPU's, counters summed)   */
-    uint32_t reserved;
+    uint32_t untimed_launches; /* launches of the dominant kernel that could not be timed (event creation failed):
+                                  main_kernel_ms is then a lower bound and must not feed a roofline                    */
     double host_ms;       /* last hvs_query: wall time of the whole call, host memory in -> host memory out (the
                              reference's timing scope, src/test.cpp:82-88); 0 for the device-resident calls          */
 } hvs_timing;

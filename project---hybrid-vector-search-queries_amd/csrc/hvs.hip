@@ -96,6 +96,7 @@ struct hvs_ctx {
     // of 10^7 queries is 10 batches x 14 levels)
     std::vector<hipEvent_t> ev_k;
     int n_launch_events = 0;  // pairs used by the current call
+    uint32_t untimed_launches = 0;
     bool timing_valid = false;
     hvs_timing timing{};
     double host_ms = 0.0;     // wall time of the last hvs_query (host memory in -> host memory out)
@@ -181,11 +182,17 @@ int kernel_timer_begin(hvs_ctx* c)
     const size_t need = 2u * (size_t)(c->n_launch_events + 1);
     while (c->ev_k.size() < need) {
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return -1;
+        if (hipEventCreate(&e) != hipSuccess) {
+            c->untimed_launches++;
+            return -1;
+        }
         c->ev_k.push_back(e);
     }
     const int ev = c->n_launch_events;
-    if (hipEventRecord(c->ev_k[2 * ev], c->stream) != hipSuccess) return -1;
+    if (hipEventRecord(c->ev_k[2 * ev], c->stream) != hipSuccess) {
+        c->untimed_launches++;
+        return -1;
+    }
     return ev;
 }
 void kernel_timer_end(hvs_ctx* c, int ev)
@@ -883,6 +890,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, A
     }
     c->timing_valid = false;
     c->n_launch_events = 0;
+    c->untimed_launches = 0;
     c->fallback_queries = 0;
     HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
@@ -1371,6 +1379,7 @@ int leaf_last_timing(hvs_ctx* c, hvs_timing* out)
     c->timing.scanned_pairs = h[1];
     c->timing.rescored_pairs = h[2];
     c->timing.fallback_queries = c->fallback_queries;
+    c->timing.untimed_launches = c->untimed_launches;
     c->timing.host_ms = c->host_ms;
     *out = c->timing;
     return HVS_OK;
@@ -1837,6 +1846,7 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
         agg.scanned_pairs += t.scanned_pairs;
         agg.rescored_pairs += t.rescored_pairs;
         agg.fallback_queries += t.fallback_queries;
+        agg.untimed_launches += t.untimed_launches;
         agg.load_ms = std::max(agg.load_ms, t.load_ms);
         agg.engine = t.engine;
         agg.n_gpus += 1;
