@@ -754,7 +754,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
     const int fmt = c->tile_fmt;
     int rc = prep_batch(c, q0, nqb, sn == c->n, fmt);
     if (rc) return rc;
-    if (fmt == HVS_FMT_I8X16 && (rc = build_items(c))) return rc;
+    if ((rc = build_items(c))) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
     HvsItems W{c->d_items, c->d_lvloff, c->d_cursor, HVS_SEG};
@@ -798,18 +798,19 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         for (uint32_t level = level0; level <= level1; ++level) {
             const uint32_t count = L.off[level + 1] - L.off[level];
             const int ev = kernel_timer_begin(c);
-            const dim3 fgrid(hvs_ceil_div(B.ngroups, HVS_WG_WAVES), hvs_ceil_div(count, HVS_SEG));
+            // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
+            const dim3 fgrid(4u * (uint32_t)c->num_cus);
+            (void)count;
             W.segsize = c->segs.seg[level];
-            if (fmt == HVS_FMT_I8X16)  // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
-                hipLaunchKernelGGL(hvs_k_filter_i8x16, dim3(4u * (uint32_t)c->num_cus), dim3(64 * HVS_WG_WAVES), 0, c->stream,
-                                   c->d_tiles_ct, c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W,
-                                   c->d_counters);
+            if (fmt == HVS_FMT_I8X16)
+                hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,
+                                   c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             else if (fmt == HVS_FMT_I8)
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_I8>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
-                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
+                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             else
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_BF16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
-                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, c->d_counters);
+                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             kernel_timer_end(c, ev);
         }
         if (fmt == HVS_FMT_I8X16)

@@ -1222,6 +1222,19 @@ __device__ __forceinline__ uint32_t hvs_hit_mask(const ACC& a, THR th)
     return m;
 }
 
+#define HVS_ITEM_QUAD_BITS 12  // item code: (segment within the level << 12) | quad of groups
+// Work items.  A launch of one level is a fixed number of workgroups that pull (quad of groups, segment) items from
+// the level's list (HvsItems, built per batch by hvs_k_item_*: only pairs whose ranges meet, ordered segment-major so
+// that concurrent workgroups stream the same tiles) with one atomic per item.  A 2-D grid over all (quad, segment)
+// pairs is mostly empty for windowed predicates -- 75 % of the workgroups of a 25 % timestamp window, > 98 % for
+// categorical ones -- and the empties cost ~7 ns each of dispatch time (18 % of a type-2 batch's filter time).
+struct HvsItems {
+    const uint32_t* list;    // items of all levels: (segment within the level << 12) | quad
+    const uint32_t* lvloff;  // [K + 2] first item of each level; lvloff[level + 1] - lvloff[level] = the level's items
+    uint32_t* cursor;        // [16] next item of each level (zeroed per batch)
+    uint32_t segsize;        // row blocks per item at the level being launched (HvsSegs::seg)
+};
+
 // operand / accumulator types and the MFMA step of the two tile formats
 template <int FMT>
 struct HvsFmt;
@@ -1261,7 +1274,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                                                             const uint4* __restrict__ nrm_t,
                                                             const uint32_t* __restrict__ bpos_ct,
                                                             const uint32_t* __restrict__ bpos_t, HvsLevels L,
-                                                            uint32_t level, HvsBatch B,
+                                                            uint32_t level, HvsBatch B, HvsItems W,
                                                             unsigned long long* __restrict__ counters)
 {
     typedef HvsFmt<FMT> F;
@@ -1275,28 +1288,37 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     __shared__ uint4 snrm[2][kI8 ? STG * HVS_I8_NRM_U4 : 1];
     __shared__ uint64_t sbuf[HVS_WG_WAVES][256];         // wave-private survivor buffers
     __shared__ uint32_t srange[HVS_WG_WAVES][2];
+    __shared__ uint32_t sitem;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    // grid: x = quad of groups (fastest), y = ABSOLUTE storage segment of the level.  Consecutive
-    // workgroups therefore stream the same 896 KiB of tiles for different queries, so a segment
+    // Work items (HvsItems): a fixed crew of workgroups pulls (quad of groups, segment) pairs of this level, ordered
+    // segment-major: consecutive items stream the same run of tiles for different queries, so a segment
     // is fetched from HBM about once and then served by the XCDs' L2s / the Infinity Cache.
     // The quad's 4 waves walk the segment together: every tile is fetched once per workgroup
     // into LDS and read from there by all 4 waves (ds_read_b128).  All groups of a quad use the
     // same ordering (the T-ordering part of a batch starts at a quad boundary).
-    const uint32_t g = blockIdx.x * HVS_WG_WAVES + wv;
-    const uint32_t gq = blockIdx.x * HVS_WG_WAVES;  // first group of the workgroup decides the ordering
+    const uint32_t item0 = W.lvloff[level], nitems = W.lvloff[level + 1u] - item0;
+  for (;;) {
+    if (threadIdx.x == 0u) sitem = atomicAdd(&W.cursor[level], 1u);
+    __syncthreads();
+    const uint32_t item = __builtin_amdgcn_readfirstlane(sitem);
+    if (item >= nitems) break;  // uniform over the workgroup
+    const uint32_t code = __builtin_amdgcn_readfirstlane(W.list[item0 + item]);
+    const uint32_t quad = code & ((1u << HVS_ITEM_QUAD_BITS) - 1u), segment = code >> HVS_ITEM_QUAD_BITS;
+    const uint32_t g = quad * HVS_WG_WAVES + wv;
+    const uint32_t gq = quad * HVS_WG_WAVES;  // first group of the workgroup decides the ordering
     const uint32_t ord = B.gord[gq];
     const uint4* __restrict__ tiles = ord ? tiles_t : tiles_ct;
     const uint32_t* __restrict__ bpos = ord ? bpos_t : bpos_ct;
     const uint4* __restrict__ nrm = ord ? nrm_t : nrm_ct;
-    const uint32_t seg_lo = L.off[level] + blockIdx.y * HVS_SEG;
+    const uint32_t seg_lo = L.off[level] + segment * W.segsize;
     uint32_t i0 = 0, i1 = 0;  // this wave's tiles [i0,i1) inside the segment (empty when i0 >= i1)
     if (g < B.ngroups && B.gord[g] == ord) {
         uint32_t lo, hi;
         hvs_level_run(L, level, B.gua[g] / 32u, hvs_ceil_div(B.gub[g], 32u), lo, hi);
-        if (seg_lo < hi && seg_lo + HVS_SEG > lo) {
+        if (seg_lo < hi && seg_lo + W.segsize > lo) {
             i0 = seg_lo > lo ? seg_lo : lo;
-            i1 = (seg_lo + HVS_SEG) < hi ? (seg_lo + HVS_SEG) : hi;
+            i1 = (seg_lo + W.segsize) < hi ? (seg_lo + W.segsize) : hi;
         }
     }
     // (computing all four groups' runs from scalars in every wave, without this LDS exchange and barrier,
@@ -1312,7 +1334,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         I0 = srange[w][0] < I0 ? srange[w][0] : I0;
         I1 = srange[w][1] > I1 ? srange[w][1] : I1;
     }
-    if (I0 >= I1) return;  // uniform over the workgroup
+    if (I0 >= I1) continue;  // uniform over the workgroup (cannot happen with a well-formed list)
     I0 = __builtin_amdgcn_readfirstlane(I0);  // (read from LDS: tell the compiler they are scalars)
     I1 = __builtin_amdgcn_readfirstlane(I1);
     i0 = __builtin_amdgcn_readfirstlane(i0);  // wave-uniform by construction: keep the tile test scalar
@@ -1565,6 +1587,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         flush();
         if (lane == 0u) atomicAdd(&counters[1], (unsigned long long)nblocks * 32ull * HVS_GROUP);
     }
+  }  // next work item (the last stage barrier has released the stage buffers)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1612,7 +1635,6 @@ __device__ __forceinline__ uint32_t hvs_hit_mask8(const hvs_i32x4& a0, const hvs
 //   hvs_k_item_scan   : exclusive prefix over all segments (one workgroup) + per-level offsets
 //   hvs_k_item_fill   : the same sweep as the count, writing (segment << 12 | quad) in quad order
 // ---------------------------------------------------------------------------------------------
-#define HVS_ITEM_QUAD_BITS 12  // item code: (segment within the level << 12) | quad of groups
 struct HvsSegs {
     uint32_t first[17];  // first global segment number of each level; first[K + 1] = total
     uint32_t seg[17];    // row blocks per work item of each level (a power of two, 8 .. HVS_SEG)
@@ -1737,18 +1759,6 @@ __global__ __launch_bounds__(1024) void hvs_k_item_scan(HvsSegs S, const uint32_
     __syncthreads();
     if (threadIdx.x <= S.K) lvloff[threadIdx.x] = segoff[S.first[threadIdx.x]];
 }
-
-// Work items.  A launch of one level is a fixed number of workgroups that pull (quad of groups, segment) items from
-// the level's list (HvsItems, built per batch by hvs_k_item_*: only pairs whose ranges meet, ordered segment-major so
-// that concurrent workgroups stream the same tiles) with one atomic per item.  A 2-D grid over all (quad, segment)
-// pairs is mostly empty for windowed predicates -- 75 % of the workgroups of a 25 % timestamp window, > 98 % for
-// categorical ones -- and the empties cost ~7 ns each of dispatch time (18 % of a type-2 batch's filter time).
-struct HvsItems {
-    const uint32_t* list;    // items of all levels: (segment within the level << 12) | quad
-    const uint32_t* lvloff;  // [K + 2] first item of each level; lvloff[level + 1] - lvloff[level] = the level's items
-    uint32_t* cursor;        // [16] next item of each level (zeroed per batch)
-    uint32_t segsize;        // row blocks per item at the level being launched (HvsSegs::seg)
-};
 
 __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filter_i8x16(
     const uint4* __restrict__ tiles_ct, const uint4* __restrict__ tiles_t, const uint4* __restrict__ nrm_ct,
