@@ -1,5 +1,7 @@
 // Host-only check of the level-interleaved block order (csrc/hvs_filter.h): every block is stored
-// exactly once, and for any block range the per-level storage runs cover exactly that range.
+// exactly once, and for any block range the per-level storage runs cover exactly that range; and of the work-item
+// segmentation (hvs_make_segs): per level the segments tile the level's storage run exactly once, their size is a
+// power of two in 8..HVS_SEG that shrinks for small batches, and the global segment numbering is gap-free.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -34,6 +36,22 @@ int main()
                 covered += hi - lo;
             }
             if (covered != (uint64_t)(bhi - blo)) { std::printf("FAIL n=%u: [%u,%u) covered %llu\n", n, blo, bhi, (unsigned long long)covered); return 1; }
+        }
+        for (uint32_t nquads : {1u, 20u, 512u, 2052u}) {
+            const HvsSegs S = hvs_make_segs(L, nquads, 512u);
+            uint32_t expect_first = 0;
+            for (uint32_t j = 0; j <= L.K; ++j) {
+                const uint32_t T = L.off[j + 1] - L.off[j], seg = S.seg[j];
+                if (seg < 8u || seg > HVS_SEG || (seg & (seg - 1u))) { std::printf("FAIL n=%u quads=%u level %u: segment size %u\n", n, nquads, j, seg); return 1; }
+                if (S.first[j] != expect_first) { std::printf("FAIL n=%u quads=%u level %u: first segment %u != %u\n", n, nquads, j, S.first[j], expect_first); return 1; }
+                const uint32_t nseg = hvs_ceil_div(T, seg);
+                if ((uint64_t)nseg * seg < T || (nseg && (uint64_t)(nseg - 1u) * seg >= T)) { std::printf("FAIL n=%u level %u: %u segments of %u for %u blocks\n", n, j, nseg, seg, T); return 1; }
+                // a small batch gets enough items to fill the workgroup slots unless the level itself is tiny
+                if (seg > 8u && (uint64_t)nseg * nquads < 1024u && T >= 8u * 2u) { std::printf("FAIL n=%u quads=%u level %u: only %u items\n", n, nquads, j, nseg * nquads); return 1; }
+                if (nseg >= (1u << 20)) { std::printf("FAIL n=%u level %u: %u segments do not fit the item code\n", n, j, nseg); return 1; }
+                expect_first += nseg;
+            }
+            if (S.first[L.K + 1] != expect_first) { std::printf("FAIL n=%u: total segments\n", n); return 1; }
         }
         std::printf("n=%u nblk=%u K=%u level0=%u blocks radices:", n, L.nblk, L.K, L.off[1] - L.off[0]);
         for (uint32_t j = 1; j <= L.K; ++j) std::printf(" %u", L.radix[j]);

@@ -237,12 +237,14 @@ def test_mfma_accumulation_error_is_inside_the_budget(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
-def test_int8_mfma_operand_layout(tmp_path):
-    """The INT8 filter's fragment layout and accumulator-init semantics of v_mfma_i32_32x32x32_i8: exact integers."""
+@pytest.mark.parametrize("src", ["mfma_i8_layout_check.hip", "mfma_i8x16_layout_check.hip"], ids=["32x32x32", "16x16x64"])
+def test_int8_mfma_operand_layout(tmp_path, src):
+    """The INT8 filters' fragment layouts and accumulator-init semantics of v_mfma_i32_32x32x32_i8 (HVS_FMT_I8) and
+    v_mfma_i32_16x16x64_i8 (HVS_FMT_I8X16, the default): exact integers."""
     import subprocess
-    exe = str(tmp_path / "mfma_i8_layout_check.out")
+    exe = str(tmp_path / (src[:-4] + ".out"))
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w",
-                    os.path.join(T.REPO, "tests", "mfma_i8_layout_check.hip"), "-o", exe], check=True, capture_output=True)
+                    os.path.join(T.REPO, "tests", src), "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     print(r.stdout)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
