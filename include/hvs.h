@@ -15,8 +15,10 @@
  *
  * Conventions: plain pointers and sizes, no exceptions, int status (0 = ok, negative =
  * HVS_E*), one hvs_ctx is used from one thread at a time (the reference has a single
- * caller, src/test.cpp:85), all work of a context runs on the context's own HIP stream
- * on one GPU.  dim = 100 is a compile-time constant like the reference's VEC_DIM (include/optimized_impl.h:28);
+ * caller, src/test.cpp:85).  A context is one GPU (hvs_create) or all GPUs of the node
+ * (hvs_create_multi); per GPU the engine runs on the context's own HIP stream, hvs_query's
+ * host transfers on two more (copy-in, copy-out), and a multi-GPU context drives each GPU
+ * from its own host thread for the duration of a call.  dim = 100 is a compile-time constant like the reference's VEC_DIM (include/optimized_impl.h:28);
  * k defaults to the reference's KNN_LIMIT = 100 (optimized_impl.h:26) and can be changed per context (hvs_set_k).
  */
 #ifndef HVS_H
