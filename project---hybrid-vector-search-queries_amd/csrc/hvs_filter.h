@@ -1930,11 +1930,18 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     auto epilogue = [&](uint32_t bpx, bool inner) {
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) {
+#ifdef HVS_EXPERIMENT_NOEPI
+            int m = imax(acc[0][j][0], acc[1][j][3]);  // ceiling experiment: 1 instead of 4 instructions per sub-block
+#else
             int m = imax(imax(acc[0][j][0], acc[0][j][1]), acc[0][j][2]);  // v_max3 chain
             m = imax(imax(m, acc[0][j][3]), acc[1][j][0]);
             m = imax(imax(m, acc[1][j][1]), acc[1][j][2]);
             m = imax(m, acc[1][j][3]);
+#endif
             hm[j] = __ballot(m >= theta[j]);
+#ifdef HVS_EXPERIMENT_NOHIT
+            hm[j] = __ballot(m == 0x7fffff37);  // keeps the max chain alive, (almost) never true: ceiling experiment
+#endif
             if (j == NSUB / 2 - 1) __builtin_amdgcn_sched_barrier(0);  // (the younger accumulators are read last)
         }
         if (!inner) {
