@@ -1606,8 +1606,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 // compare against the lane's threshold, scalar hit masks; survivors leave as 8-byte entries (hvs_entry16_*).
 // ---------------------------------------------------------------------------------------------
 #define HVS_HITMASK8_ASM                                                                                                 \
-    "v_mov_b32 %0, 0\n\tv_cmp_ge_i32_e64 %1, %12, %13\n\tv_cmp_ge_i32_e64 %2, %11, %13\n\tv_cmp_ge_i32_e64 %3, %10, %13\n\t" \
-    "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_ge_i32_e64 %1, %9, %13\n\t"                                            \
+    "v_cmp_ge_i32_e64 %1, %12, %13\n\tv_cmp_ge_i32_e64 %2, %11, %13\n\tv_cmp_ge_i32_e64 %3, %10, %13\n\t"                    \
+    "v_addc_co_u32_e64 %0, %4, 0, 0, %1\n\tv_cmp_ge_i32_e64 %1, %9, %13\n\t"                                                \
     "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_ge_i32_e64 %2, %8, %13\n\t"                                            \
     "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_ge_i32_e64 %3, %7, %13\n\t"                                            \
     "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_ge_i32_e64 %1, %6, %13\n\t"                                            \
@@ -1949,15 +1949,21 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
             for (int j = 0; j < NSUB; ++j) hm[j] &= __ballot(bpx * 32u + 32u > ra[j]) & __ballot(bpx * 32u < rb[j]);
         }
     };
-    auto survivors = [&](int j, uint32_t bpx, bool inner) {
-        uint32_t mask = hvs_hit_mask8(acc[0][j], acc[1][j], theta[j]);
-        if (!inner) mask = ((bpx * 32u + 32u > ra[j]) & (bpx * 32u < rb[j])) ? mask : 0u;
-        const uint32_t slot = g * HVS_GROUP + j * HVS_I8X16_QSUB + (lane & 15u);
-        const uint64_t nz = __ballot(mask != 0u);
-        if (mask != 0u) lbuf[wcnt + hvs_prefix_count(nz)] = hvs_entry16_make(slot, bpx, lane >> 4, mask);
+    // hm[j] is EXACTLY the set of lanes that have an entry to write: a lane's max reached its threshold iff one of its 8
+    // accumulators did (mask != 0), and outside `inner` tiles hm[j] already carries the lane's range test -- so the
+    // lane set needs no second compare, ballot or range test: the scalar mask becomes the execution mask directly
+    // (s_and_saveexec) and the prefix count / popcount come from it
+    auto survivors = [&](int j, uint32_t bpx) {
+        const uint32_t mask = hvs_hit_mask8(acc[0][j], acc[1][j], theta[j]);
+        const uint64_t nz = hm[j];
+        if (__builtin_amdgcn_inverse_ballot_w64(nz)) {
+            const uint32_t slot = g * HVS_GROUP + j * HVS_I8X16_QSUB + (lane & 15u);
+            lbuf[wcnt + hvs_prefix_count(nz)] = hvs_entry16_make(slot, bpx, lane >> 4, mask);
+        }
         wcnt += (uint32_t)__popcll(nz);
         if (wcnt > 192u) flush();
     };
+
     uint32_t ra_max = 0u, rb_min = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
@@ -1991,7 +1997,7 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         if (any != 0ull) {
 #pragma unroll
             for (int j = 0; j < NSUB; ++j)
-                if (hm[j] != 0ull) survivors(j, bpx, inner);
+                if (hm[j] != 0ull) survivors(j, bpx);
         }
     };
     for (uint32_t st = 0; st < nstage; ++st) {
