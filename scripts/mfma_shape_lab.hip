@@ -10,6 +10,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 scripts/mfma_shape_lab.hip -o shape_lab.out
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void bare(const uint4* __restrict__ in, int
 // ---- part 2 ---------------------------------------------------------------------------------------------
 #define TILE_U4 (4 * 64 + 8)  // 4 KiB of A fragments + 32 int32 accumulator inits
 #define STG 8
-template <int SHAPE16, int OCC>
+template <int SHAPE16, int OCC, int PRIO = 0>
 __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, int* __restrict__ out, int ntiles, int theta_in)
 {
     __shared__ uint4 stile[2][STG * TILE_U4];
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
                 }
                 // af[0], af[1]: row block 0, k-steps 0, 1;  af[2], af[3]: row block 1
                 i32x4 acc[2][8];
+                if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3);  // the multiplying wave keeps the matrix pipe
+                if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
                         acc[rb][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * rb + 1], bq[2 * q + 1], acc[rb][q], 0, 0, 0);
+                if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);  // the wave in its epilogue goes first
                 bool anyhit = false;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -156,6 +161,126 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
     out[blockIdx.x * 256 + threadIdx.x] = keep + (int)hits;
 }
 
+// ---- part 4: the 16x16x64 loop software-pipelined by HALF tiles inside each wave: the 16 matrix instructions of half-tile
+// h (16 rows x 128 queries x K=128) are interleaved with the max/threshold epilogue of half-tile h-1 (the other accumulator
+// set) -- 1.5 vector instructions per matrix-instruction gap -- and the LDS reads of half-tile h+1 follow the last read of
+// the current fragments.  Same registers as the phase-separated loop of part 2 (two sets of 8 accumulator blocks).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void loop_pipe(const uint4* __restrict__ in, int* __restrict__ out, int ntiles, int theta_in)
+{
+    __shared__ uint4 stile[2][STG * TILE_U4];
+    __shared__ uint4 spad[OCC == 1 ? 2048 : 1];
+    if (ntiles < 0) spad[threadIdx.x % (OCC == 1 ? 2048 : 1)] = in[threadIdx.x];
+    const unsigned lane = threadIdx.x & 63u;
+    union { uint4 u; i32x4 v; } c;
+    i32x4 bq[16];
+    for (int q = 0; q < 16; ++q) {
+        c.u = in[(q % 20) * 64 + lane];
+        bq[q] = c.v;
+        asm volatile("" : "+v"(bq[q]));
+    }
+    for (int e = threadIdx.x; e < 2 * STG * TILE_U4; e += 256) (&stile[0][0])[e] = in[(e * 7) % (20 * 64)];
+    __syncthreads();
+    int theta[8];
+    for (int q = 0; q < 8; ++q) theta[q] = theta_in + q;
+    int keep = 0;
+    unsigned hits = 0;
+    i32x4 accA[8], accB[8];
+    for (int j = 0; j < 8; ++j) accA[j] = accB[j] = i32x4{0, 0, 0, 0};
+    i32x4 af0, af1, nh;  // fragments (k-steps 0, 1) and accumulator inits of the half-tile being multiplied
+    auto load_half = [&](unsigned cur, int tt, int rb) {
+        c.u = stile[cur][tt * TILE_U4 + (2 * rb) * 64 + lane]; af0 = c.v;
+        c.u = stile[cur][tt * TILE_U4 + (2 * rb + 1) * 64 + lane]; af1 = c.v;
+        c.u = stile[cur][tt * TILE_U4 + 256 + 4 * rb + (lane >> 4)]; nh = c.v;
+    };
+    // one half-tile: cur <- af * bq + nh (16 matrix instructions), epilogue of prv in the gaps; hm = lanes of prv at/above threshold
+    auto half = [&](i32x4 (&cur)[8], const i32x4 (&prv)[8], unsigned long long (&hm)[8], unsigned long long& any) {
+        int t[8];
+        any = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(cur[j]) : "v"(af0), "v"(bq[2 * j]), "v"(nh));
+            if (j & 1) {
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(t[j >> 1]) : "v"(prv[j >> 1][3]));
+                asm volatile("v_cmp_ge_i32_e64 %0, %1, %2" : "=s"(hm[j >> 1]) : "v"(t[j >> 1]), "v"(theta[j >> 1]));
+            } else {
+                asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(t[j >> 1]) : "v"(prv[j >> 1][0]), "v"(prv[j >> 1][1]), "v"(prv[j >> 1][2]));
+                if (j) asm volatile("s_or_b64 %0, %0, %1" : "+s"(any) : "s"(hm[(j >> 1) - 1]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(cur[j]) : "v"(af1), "v"(bq[2 * j + 1]));
+            if (j & 1) {
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(t[4 + (j >> 1)]) : "v"(prv[4 + (j >> 1)][3]));
+                asm volatile("v_cmp_ge_i32_e64 %0, %1, %2" : "=s"(hm[4 + (j >> 1)]) : "v"(t[4 + (j >> 1)]), "v"(theta[4 + (j >> 1)]));
+            } else {
+                asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(t[4 + (j >> 1)]) : "v"(prv[4 + (j >> 1)][0]), "v"(prv[4 + (j >> 1)][1]), "v"(prv[4 + (j >> 1)][2]));
+                asm volatile("s_or_b64 %0, %0, %1" : "+s"(any) : "s"(hm[3 + (j >> 1)]));
+            }
+        }
+        asm volatile("s_or_b64 %0, %0, %1" : "+s"(any) : "s"(hm[7]));
+    };
+    const int nstage = ntiles / STG;
+    load_half(0u, 0, 0);
+    for (int st = 0; st < nstage; ++st) {
+        const unsigned cur = st & 1;
+#pragma unroll 1
+        for (int tt = 0; tt < STG; ++tt) {
+            unsigned long long hm[8], any;
+            half(accA, accB, hm, any);            // rows 0..15 of tile tt; epilogue of the previous tile's rows 16..31
+            load_half(cur, tt, 1);
+            if (any) { hits++; keep += accB[0][3]; }
+            half(accB, accA, hm, any);            // rows 16..31; epilogue of rows 0..15
+            load_half(cur, tt + 1 < STG ? tt + 1 : tt, 0);
+            if (any) { hits++; keep += accA[0][3]; }
+        }
+        __syncthreads();
+    }
+    if (ntiles < 0) keep += (int)spad[(threadIdx.x ^ 1) % (OCC == 1 ? 2048 : 1)].x;
+    out[blockIdx.x * 256 + threadIdx.x] = keep + (int)hits + accA[1][0] + accB[1][0];
+}
+
+// ---- part 3: bare chains on RANDOM operands, inline asm (no compiler shuffles), 16 independent accumulator blocks per wave:
+// the chip's power / clock ceiling for each shape with nothing but matrix instructions in the loop
+template <int SHAPE16, int OCC>
+__global__ __launch_bounds__(256, OCC) void bare_random(const uint4* __restrict__ in, int* __restrict__ out, int iters)
+{
+    __shared__ uint4 spad[OCC == 1 ? 6144 : 1];  // 96 KiB: one workgroup per CU = one wave per SIMD
+    if (iters < 0) spad[threadIdx.x % (OCC == 1 ? 6144 : 1)] = in[threadIdx.x];
+    const unsigned lane = threadIdx.x & 63u;
+    union { uint4 u; i32x4 v; } c;
+    i32x4 a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        c.u = in[(i * 3 + 1) * 64 + lane]; a[i] = c.v;
+        c.u = in[(i * 5 + 2) * 64 + lane]; b[i] = c.v;
+    }
+    int keep = 0;
+    if constexpr (SHAPE16) {
+        i32x4 acc[16];
+        for (int j = 0; j < 16; ++j) acc[j] = i32x4{j, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a[j & 3]), "v"(b[(j >> 2) & 3]));
+        }
+        for (int j = 0; j < 16; ++j) keep += acc[j][0];
+    } else {
+        i32x16 acc[4];
+        for (int j = 0; j < 4; ++j) acc[j] = i32x16{j, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a[r]), "v"(b[j]));
+        }
+        for (int j = 0; j < 4; ++j) keep += acc[j][0];
+    }
+    if (iters < 0) keep += (int)spad[(threadIdx.x ^ 1) % (OCC == 1 ? 6144 : 1)].x;
+    out[blockIdx.x * 256 + threadIdx.x] = keep;
+}
+
 static float run(void (*launch)(int), int reps)
 {
     hipEvent_t a, b;
@@ -178,9 +303,12 @@ static uint4* g_in;
 static int* g_out;
 static int g_iters = 20000, g_tiles = 8192;
 template <int S> static void l_bare(int) { hipLaunchKernelGGL(bare<S>, dim3(256), dim3(256), 0, 0, g_in, g_out, g_iters); }
+template <int S, int O> static void l_brand(int) { hipLaunchKernelGGL((bare_random<S, O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_iters); }
+template <int O> static void l_pipe(int) { hipLaunchKernelGGL((loop_pipe<O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
+template <int P> static void l_prio(int) { hipLaunchKernelGGL((loop<1, 2, P>), dim3(2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
 template <int S, int O> static void l_loop(int) { hipLaunchKernelGGL((loop<S, O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
 
-int main()
+int main(int argc, char** argv)
 {
     std::vector<unsigned> h(20 * 64 * 4, 0x01010101u);
     hipMalloc(&g_in, h.size() * 4);
@@ -199,6 +327,15 @@ int main()
         h[i] = (unsigned)(st >> 32);
     }
     hipMemcpy(g_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    if (argc > 2 && !std::strcmp(argv[1], "hold")) {  // keep ONE kernel running for ~4 s so rocm-smi can sample clocks/power under it
+        void (*f)(int) = !std::strcmp(argv[2], "bare16") ? l_brand<1, 2> : !std::strcmp(argv[2], "bare32") ? l_brand<0, 2> :
+                         !std::strcmp(argv[2], "loop16") ? l_loop<1, 2> : !std::strcmp(argv[2], "pipe16") ? l_pipe<2> : l_pipe<1>;
+        double total = 0;
+        int launches = 0;
+        while (total < 4000.0) { total += run(f, 5) * 5; launches += 5; }
+        std::printf("hold %s: %d launches, %.2f ms each\n", argv[2], launches, total / launches);
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         const float a2 = run(l_loop<0, 2>, 3), b2 = run(l_loop<1, 2>, 3), a1 = run(l_loop<0, 1>, 3), b1 = run(l_loop<1, 1>, 3);
         const double pb2 = 2048.0 * 4 * g_tiles * 4, pb1 = 1024.0 * 4 * g_tiles * 4;  // 32x32 pair blocks
@@ -206,6 +343,26 @@ int main()
                     pb2 / (a2 * 1e-3) / 1e9, b2, pb2 / (b2 * 1e-3) / 1e9, a2 / b2);
         std::printf("loop random  1 wave /SIMD: 32x32x32 %.2f ms %.2f G pair-blocks/s | 16x16x64 %.2f ms %.2f G  (ratio %.3f)\n", a1,
                     pb1 / (a1 * 1e-3) / 1e9, b1, pb1 / (b1 * 1e-3) / 1e9, a1 / b1);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        const float p2 = run(l_pipe<2>, 3), p1 = run(l_pipe<1>, 3);
+        std::printf("loop random, half-tile software pipeline, 16x16x64: 2 waves/SIMD %.2f ms %.2f G pair-blocks/s | 1 wave/SIMD %.2f ms %.2f G\n", p2,
+                    2048.0 * 4 * g_tiles * 4 / (p2 * 1e-3) / 1e9, p1, 1024.0 * 4 * g_tiles * 4 / (p1 * 1e-3) / 1e9);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        const float q1 = run(l_prio<1>, 3), q2 = run(l_prio<2>, 3);
+        std::printf("loop random 16x16x64 2 waves/SIMD with s_setprio: high while multiplying %.2f ms %.2f G | high in the epilogue %.2f ms %.2f G\n", q1,
+                    2048.0 * 4 * g_tiles * 4 / (q1 * 1e-3) / 1e9, q2, 2048.0 * 4 * g_tiles * 4 / (q2 * 1e-3) / 1e9);
+    }
+    // part 3: per iteration a wave issues 16 instructions = 4 (32x32x32: 16 x 65536 MAC... ) resp. 1 (16x16x64) pair blocks of 32x32x128
+    for (int rep = 0; rep < 2; ++rep) {
+        const float x2 = run(l_brand<0, 2>, 3), y2 = run(l_brand<1, 2>, 3), x1 = run(l_brand<0, 1>, 3), y1 = run(l_brand<1, 1>, 3);
+        // pair blocks (32 rows x 32 queries x K=128) per launch: 32x32x32: 16 instr = 4 blocks; 16x16x64: 16 instr = 2 blocks
+        const double w2 = 2048.0 * 4 * g_iters, w1 = 1024.0 * 4 * g_iters;
+        std::printf("bare random 2 waves/SIMD: 32x32x32 %.2f ms %.2f G pair-blocks/s | 16x16x64 %.2f ms %.2f G\n", x2, w2 * 4 / (x2 * 1e-3) / 1e9, y2,
+                    w2 * 2 / (y2 * 1e-3) / 1e9);
+        std::printf("bare random 1 wave /SIMD: 32x32x32 %.2f ms %.2f G pair-blocks/s | 16x16x64 %.2f ms %.2f G\n", x1, w1 * 4 / (x1 * 1e-3) / 1e9, y1,
+                    w1 * 2 / (y1 * 1e-3) / 1e9);
     }
     return 0;
 }
