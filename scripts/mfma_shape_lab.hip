@@ -161,6 +161,81 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
     out[blockIdx.x * 256 + threadIdx.x] = keep + (int)hits;
 }
 
+// ---- part 5: narrower waves.  NSUB sub-blocks of 16 queries per wave (8 = the kernel's 128 queries; 4 = 64 queries), WAVES waves
+// per workgroup sharing the staged tiles, two workgroups per CU: NSUB = 4 with 8 waves per workgroup is FOUR waves per SIMD at
+// <= 128 registers -- the same LDS footprint and query coverage per workgroup, half the matrix work per tile and wave (the
+// fragment reads and the loop overhead are amortised over 16 instead of 32 matrix instructions), but four waves to fill the pipe.
+template <int NSUB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void loop_narrow(const uint4* __restrict__ in, int* __restrict__ out, int ntiles, int theta_in)
+{
+    __shared__ uint4 stile[2][STG * TILE_U4];
+    const unsigned lane = threadIdx.x & 63u;
+    union { uint4 u; i32x4 v; } c;
+    i32x4 bq[NSUB][2];
+    for (int q = 0; q < NSUB; ++q)
+        for (int ks = 0; ks < 2; ++ks) {
+            c.u = in[((2 * q + ks + (threadIdx.x >> 6)) % 20) * 64 + lane];
+            bq[q][ks] = c.v;
+            asm volatile("" : "+v"(bq[q][ks]));
+        }
+    for (int e = threadIdx.x; e < 2 * STG * TILE_U4; e += 64 * WAVES) (&stile[0][0])[e] = in[(e * 7) % (20 * 64)];
+    __syncthreads();
+    int theta[NSUB];
+    for (int q = 0; q < NSUB; ++q) theta[q] = theta_in + q;
+    int keep = 0;
+    unsigned hits = 0;
+    const int nstage = ntiles / STG;
+    i32x4 af[4], nrm[2];
+    auto load_tile = [&](unsigned cur, int tt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c.u = stile[cur][tt * TILE_U4 + s * 64 + lane];
+            af[s] = c.v;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            c.u = stile[cur][tt * TILE_U4 + 256 + 4 * rb + (lane >> 4)];
+            nrm[rb] = c.v;
+        }
+    };
+    load_tile(0u, 0);
+    for (int st = 0; st < nstage; ++st) {
+        const unsigned cur = st & 1;
+#pragma unroll 1
+        for (int tt = 0; tt < STG; ++tt) {
+            i32x4 acc[2][NSUB];
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(acc[rb][q]) : "v"(af[2 * rb]), "v"(bq[q][0]), "v"(nrm[rb]));
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[rb][q]) : "v"(af[2 * rb + 1]), "v"(bq[q][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            load_tile(cur, tt + 1 < STG ? tt + 1 : tt);  // (the next tile's reads travel under the epilogue)
+            __builtin_amdgcn_sched_barrier(0);
+            bool anyhit = false;
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q) {
+                int m = max(max(acc[0][q][0], acc[0][q][1]), acc[0][q][2]);
+                m = max(max(m, acc[0][q][3]), acc[1][q][0]);
+                m = max(max(m, acc[1][q][1]), acc[1][q][2]);
+                m = max(m, acc[1][q][3]);
+                anyhit = anyhit | (m >= theta[q]);
+            }
+            if (__ballot(anyhit) != 0ull) {
+                hits++;
+                keep += acc[0][0][3];
+            }
+        }
+        __syncthreads();
+    }
+    out[blockIdx.x * 64 * WAVES + threadIdx.x] = keep + (int)hits;
+}
+
 // ---- part 4: the 16x16x64 loop software-pipelined by HALF tiles inside each wave: the 16 matrix instructions of half-tile
 // h (16 rows x 128 queries x K=128) are interleaved with the max/threshold epilogue of half-tile h-1 (the other accumulator
 // set) -- 1.5 vector instructions per matrix-instruction gap -- and the LDS reads of half-tile h+1 follow the last read of
@@ -306,6 +381,7 @@ template <int S> static void l_bare(int) { hipLaunchKernelGGL(bare<S>, dim3(256)
 template <int S, int O> static void l_brand(int) { hipLaunchKernelGGL((bare_random<S, O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_iters); }
 template <int O> static void l_pipe(int) { hipLaunchKernelGGL((loop_pipe<O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
 template <int P> static void l_prio(int) { hipLaunchKernelGGL((loop<1, 2, P>), dim3(2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
+template <int NS, int WV> static void l_narrow(int) { hipLaunchKernelGGL((loop_narrow<NS, WV>), dim3(2048), dim3(64 * WV), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
 template <int S, int O> static void l_loop(int) { hipLaunchKernelGGL((loop<S, O>), dim3(O == 1 ? 1024 : 2048), dim3(256), 0, 0, g_in, g_out, g_tiles, 0x7fffff00); }
 
 int main(int argc, char** argv)
@@ -353,6 +429,13 @@ int main(int argc, char** argv)
         const float q1 = run(l_prio<1>, 3), q2 = run(l_prio<2>, 3);
         std::printf("loop random 16x16x64 2 waves/SIMD with s_setprio: high while multiplying %.2f ms %.2f G | high in the epilogue %.2f ms %.2f G\n", q1,
                     2048.0 * 4 * g_tiles * 4 / (q1 * 1e-3) / 1e9, q2, 2048.0 * 4 * g_tiles * 4 / (q2 * 1e-3) / 1e9);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        const float n84 = run(l_narrow<8, 4>, 3), n48 = run(l_narrow<4, 8>, 3), n44 = run(l_narrow<4, 4>, 3);
+        // pair blocks per launch: 2048 workgroups x waves x tiles x (NSUB / 2)
+        std::printf("loop random 16x16x64 asm chains: 128 queries/wave, 2 waves/SIMD %.2f ms %.2f G | 64 queries/wave, 4 waves/SIMD %.2f ms %.2f G | "
+                    "64 queries/wave, 2 waves/SIMD %.2f ms %.2f G\n", n84, 2048.0 * 4 * g_tiles * 4 / (n84 * 1e-3) / 1e9, n48,
+                    2048.0 * 8 * g_tiles * 2 / (n48 * 1e-3) / 1e9, n44, 2048.0 * 4 * g_tiles * 2 / (n44 * 1e-3) / 1e9);
     }
     // part 3: per iteration a wave issues 16 instructions = 4 (32x32x32: 16 x 65536 MAC... ) resp. 1 (16x16x64) pair blocks of 32x32x128
     for (int rep = 0; rep < 2; ++rep) {
