@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
