@@ -703,8 +703,11 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
     }
 }
 
+#ifndef HVS_BIN_QUERIES
+#define HVS_BIN_QUERIES 0u   // 0: sqrt rule below; otherwise a fixed number of queries per start-position bin (A/B builds)
+#endif
 // `counts`: the batch's class populations (hvs_k_count_classes) -- read on the device, so that forming a batch needs
-// no host round trip: ~4096 queries of a class per start-position bin
+// no host round trip
 __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
                                   const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
                                   const uint32_t* __restrict__ counts, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
@@ -715,7 +718,13 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     const uint32_t rk = hvs_type_rank(p.type);
     uint32_t a, b;
     hvs_query_range(p, keys_ct, keys_t, n, a, b);
-    uint32_t nbins = counts[rk] / 4096u;
+#if HVS_BIN_QUERIES
+    uint32_t nbins = counts[rk] / HVS_BIN_QUERIES;
+#else
+    // as many start-position bins as there are quads of 512 queries per bin: a quad's spread of range STARTS (one bin) and of
+    // range ENDS (its share of the bin, which is sorted by end) are then about the same fraction of the data
+    uint32_t nbins = (uint32_t)__builtin_sqrtf((float)counts[rk] * (1.0f / (float)(HVS_WG_WAVES * HVS_GROUP)));
+#endif
     nbins = nbins < 1u ? 1u : (nbins > 4096u ? 4096u : nbins);
     const uint32_t abin = (uint32_t)(((uint64_t)a * nbins) / ((uint64_t)n + 1ull));
     keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
