@@ -86,7 +86,7 @@ int hvs_device_count(void);
 #define HVS_GATHER_DIRECT 0
 #define HVS_GATHER_PEER 1
 int hvs_set_gather(hvs_ctx *ctx, int mode);
-/* Announce the size of the coming calls: query/result buffers and the per-batch workspace (~17 GB for batches of 2^20
+/* Announce the size of the coming calls: query/result buffers and the per-batch workspace (~34 GB for batches of 2^21
  * queries) are allocated now (and again after a later hvs_load_data) instead of inside the first query. */
 int hvs_reserve(hvs_ctx *ctx, uint32_t nq);
 void hvs_destroy(hvs_ctx *ctx);

@@ -1231,7 +1231,7 @@ __device__ __forceinline__ uint32_t hvs_hit_mask(const ACC& a, THR th)
     return m;
 }
 
-#define HVS_ITEM_QUAD_BITS 12  // item code: (segment within the level << 12) | quad of groups
+#define HVS_ITEM_QUAD_BITS 13  // item code: (segment within the level << 13) | quad of groups (2^13 quads = 2^22 query slots)
 // Work items.  A launch of one level is a fixed number of workgroups that pull (quad of groups, segment) items from
 // the level's list (HvsItems, built per batch by hvs_k_item_*: only pairs whose ranges meet, ordered segment-major so
 // that concurrent workgroups stream the same tiles) with one atomic per item.  A 2-D grid over all (quad, segment)
