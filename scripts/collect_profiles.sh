@@ -7,14 +7,14 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
-python bench.py > $OUT/bench_default_n1e7_b1048576_mixed.json 2> $OUT/bench_default.err
+python bench.py > $OUT/bench_default_n1e7_b2097152_mixed.json 2> $OUT/bench_default.err
 python bench.py --force-type 0 --batch 262144 --cpu-seconds 0 --no-e2e > $OUT/bench_type0_n1e7_b262144.json 2>/dev/null
-HVS_I8_SHAPE=32 python bench.py --cpu-seconds 0 --no-e2e > $OUT/bench_i8_32x32x32_n1e7_b1048576_mixed.json 2>/dev/null
-python bench.py --engine 2 --cpu-seconds 0 --no-e2e > $OUT/bench_bf16_filter_n1e7_b1048576_mixed.json 2>/dev/null
+HVS_I8_SHAPE=32 python bench.py --cpu-seconds 0 --no-e2e > $OUT/bench_i8_32x32x32_n1e7_b2097152_mixed.json 2>/dev/null
+python bench.py --engine 2 --cpu-seconds 0 --no-e2e > $OUT/bench_bf16_filter_n1e7_b2097152_mixed.json 2>/dev/null
 python bench.py --engine 1 --batch 16384 --cpu-seconds 0 --no-e2e > $OUT/bench_exact_engine_n1e7_b16384_mixed.json 2>/dev/null
 python bench.py --n 1000000 --batch 10000 --force-type 0 --steps 5 --warmup 2 --cpu-seconds 0 > $OUT/bench_config1_n1e6_q1e4_type0.json 2>/dev/null
 python bench.py --n 1000000 --batch 10000 --steps 5 --warmup 2 --cpu-seconds 0 > $OUT/bench_config2_n1e6_q1e4_mixed.json 2>/dev/null
-python bench.py --n 100000000 --steps 2 --warmup 1 --cpu-seconds 0 > $OUT/bench_n1e8_b1048576_mixed.json 2>/dev/null
+python bench.py --n 100000000 --steps 2 --warmup 1 --cpu-seconds 0 > $OUT/bench_n1e8_b2097152_mixed.json 2>/dev/null
 python bench.py --force-dist --cpu-seconds 0 --no-e2e > $OUT/bench_force_dist_rehearsal.json 2>/dev/null
 echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
