@@ -9,7 +9,7 @@ PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
 
 def case(rng, i):
     n = int(rng.choice([100, 101, 1000, 4095, 4096, 5000, 33000, 70000, 200000, 1000003]))
-    nq = int(rng.choice([1, 31, 33, 128, 129, 1000, 5000]))
+    nq = int(rng.choice([1, 31, 33, 128, 129, 1000, 5000, 5000, 20000, 66000]))   # (the large ones: several start-position bins per class)
     ncat = int(rng.choice([1, 2, 7, 100, 5000]))
     profile = int(rng.choice([0, 1, 1, 1]))
     nodes = T.gen_data(n, int(rng.integers(1 << 30)), profile, ncat)
