@@ -190,6 +190,12 @@ def main():
                          "evaluated_pairs_per_launch": scanned / max(kern_launches, 1),
                          "device_query_ms_per_step": query_ms / a.steps,
                          "rescored_pairs_per_query": rescored / max(a.batch * a.steps, 1),
+                         # SURVEY 8d's second figure: what a one-query-at-a-time scan (the reference) would have to fetch,
+                         # 8 B of attributes per scanned row + 400 B per passing row, over the step time and the 8 TB/s peak
+                         # per GPU.  An EFFECTIVE figure: batching is why it exceeds 1; the real traffic is `traffic`.
+                         # (per GPU: rank 0's own queries and pairs)
+                         "effective_hbm_frac_of_a_per_query_scan": ((8.0 * a.n * a.batch * a.steps + 400.0 * pairs) / elapsed / 1e9)
+                                                                   / HBM_PEAK_GBS,
                          # context, not the peak: a bare loop of the same MFMA chains sustains this much on random
                          # operands on this chip (DVFS; scripts/mfma_loop_lab.hip / mfma_i8_lab.hip -DLAB_RANDOM)
                          # context, not the peak: what the filter-shaped loop (LDS fragment reads, epilogue, 2 waves/SIMD)
