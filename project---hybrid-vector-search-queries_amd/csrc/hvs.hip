@@ -855,8 +855,10 @@ int resolve_overflow(hvs_ctx* c)
 // `after_batch(off, nqb)`: called after the kernels of each batch have been enqueued (the host pipeline of hvs_query
 // hangs its copies there); queries [q0 + off, q0 + off + nqb) are complete on the stream at that point, except for
 // overflowed ones (resolve_overflow)
+// `host_pipeline` (hvs_query): the first and the last batch of a call are small (kBatchMfma / 8), because the first batch's
+// queries and the last batch's results are the only transfers the pipeline cannot hide; the batches between share the rest evenly
 template <typename AfterBatch>
-int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, AfterBatch after_batch)
+int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, AfterBatch after_batch, bool host_pipeline = false)
 {
     if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
     if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
@@ -898,8 +900,23 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, A
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
     const uint32_t step = mfma ? kBatchMfma : kBatch;
-    for (uint32_t off = 0; off < nq; off += step) {
-        const uint32_t nqb = std::min(step, nq - off);
+    const uint32_t edge = kBatchMfma / 8u;
+    const bool ramp = host_pipeline && mfma && edge >= 1024u && nq >= 4u * edge;
+    uint32_t middle_left = 0, middle_batches = 0;
+    if (ramp) {
+        middle_left = nq - 2u * edge;
+        middle_batches = hvs_ceil_div(middle_left, step);
+    }
+    for (uint32_t off = 0, nqb = 0; off < nq; off += nqb) {
+        if (!ramp) {
+            nqb = std::min(step, nq - off);
+        } else if (off == 0u || nq - off <= edge) {
+            nqb = std::min(edge, nq - off);
+        } else {  // the middle: equal shares, whole quads of 512 queries
+            nqb = std::min(middle_left, hvs_ceil_div(hvs_ceil_div(middle_left, middle_batches), 512u) * 512u);
+            middle_left -= nqb;
+            middle_batches -= 1u;
+        }
         int rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
                       : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
         if (rc) return rc;
@@ -1323,7 +1340,7 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
         return HVS_OK;
     };
-    if ((rc = send_input(ahead))) return rc;
+    if ((rc = send_input(std::max(kBatch, kBatchMfma / 8u)))) return rc;  // (run_queries' first batch in pipeline mode)
     auto after_batch = [&](uint32_t off, uint32_t nqb) -> int {
         const uint32_t done_q = off + nqb;
         int r2;
@@ -1333,7 +1350,7 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         HVS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_batch, 0));
         return HVS_OK;
     };
-    if ((rc = run_queries(c, 0, nq, sample_proportion, after_batch))) return rc;
+    if ((rc = run_queries(c, 0, nq, sample_proportion, after_batch, true))) return rc;
     if ((rc = copy_out_until(npieces))) return rc;
     while (!out_pinned && out_drained < out_enq)
         if ((rc = drain_one())) return rc;
