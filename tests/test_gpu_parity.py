@@ -611,8 +611,9 @@ def test_multi_gpu_context_virtual_ranks(engine):
 
 
 def test_host_pipeline_many_pieces_and_caller_buffers():
-    """hvs_query is a pipeline of 65536-query pieces (pinned staging, H2D one batch ahead, D2H under the next batch):
-    a call of several pieces and several batches must return exactly what the resident path returns."""
+    """hvs_query is a pipeline of 65536-query pieces (pinned staging, H2D one batch ahead, D2H under the next batch) over
+    batches that do not end on piece boundaries (small first and last batch, equal shares between): a call of several
+    pieces and several batches must return exactly what the resident path returns."""
     import subprocess
     import sys
     code = r"""
@@ -620,7 +621,7 @@ import importlib, sys, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import hvs_testlib as T
 PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
-n, nq = 200_000, 300_000                      # 5 staging pieces, 3 batches of 131072
+n, nq = 200_000, 300_000                      # 5 staging pieces; batches of 16384 (first, last) and 3 x ~89k queries between
 nodes = T.gen_data(n, 55, T.GEN_V1, 50); queries = T.gen_queries(nq, 56, T.GEN_V1, 50)
 queries[70000, 8] = np.inf; queries[299999, 9] = np.inf     # fallback queries in the first and the last piece
 with PKG.Engine(0) as e:
