@@ -1901,12 +1901,16 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     hvs_i32x4 acc[2][NSUB];
     uint64_t hm[NSUB];
     uint32_t bp = 0;
-    auto load_tile = [&](uint32_t i) {
-        const uint32_t rel = i - I0, buf = (rel / STG) & 1u, tt = rel % STG;
+    // tile i of the staged run; `slot` = its place in the two stage buffers (buffer * STG + tile within the stage): the
+    // caller steps it by one per tile instead of deriving it from i (scalar instructions are not free in this loop)
+    const uint4* stile_flat = &stile[0][0];
+    const uint4* snrm_flat = &snrm[0][0];
+    auto load_tile = [&](uint32_t i, uint32_t slot) {
 #pragma unroll
-        for (int f = 0; f < HVS_I8X16_FRAGS; ++f) af[f] = hvs_as_i32x4(stile[buf][tt * TILE_U4 + f * 64 + lane]);
+        for (int f = 0; f < HVS_I8X16_FRAGS; ++f) af[f] = hvs_as_i32x4(stile_flat[slot * TILE_U4 + f * 64 + lane]);
+        const uint32_t nslot = (slot / STG) * 64u + (slot % STG) * NRM_U4;  // (snrm rows are 64 uint4 per stage buffer)
 #pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) nh[r2] = hvs_as_i32x4(snrm[buf][tt * NRM_U4 + 4 * r2 + (lane >> 4)]);
+        for (int r2 = 0; r2 < 2; ++r2) nh[r2] = hvs_as_i32x4(snrm_flat[nslot + 4 * r2 + (lane >> 4)]);
         bp = __builtin_amdgcn_readfirstlane(bpos[i]);
     };
     // The 32 matrix instructions of a tile in two groups of 16 (k-step 0 of every accumulator block, then k-step 1,
@@ -1998,9 +2002,9 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // Tile t: [32 matrix instructions] [LDS reads of tile t+1's fragments, when it sits in the same stage] [epilogue of
     // tile t] [survivors, rarely].  The fragment registers are dead once the last matrix instruction has issued, so the
     // next tile's reads travel under the epilogue's ~50 vector instructions instead of in front of the next matrix block.
-    auto tile_body = [&](uint32_t bpx, bool inner, uint32_t inext) {
+    auto tile_body = [&](uint32_t bpx, bool inner, uint32_t inext, uint32_t slot_next) {
         chains();
-        load_tile(inext);  // (always: a conditional load would make the compiler copy the 24 fragment registers per tile)
+        load_tile(inext, slot_next);  // (always: a conditional load would make the compiler copy the 24 fragment registers per tile)
         __builtin_amdgcn_sched_barrier(0);
         epilogue(bpx, inner);
 #if HVS_HIT_TREE
@@ -2048,15 +2052,18 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         const uint32_t t0 = i0 > s0 ? i0 : s0;
         const uint32_t t1 = i1 < s0 + STG ? i1 : s0 + STG;  // (i1 <= I1)
         if (active && t0 < t1) {
-            load_tile(t0);
+            uint32_t slot = (st & 1u) * STG + (t0 - s0);
+            load_tile(t0, slot);
 #pragma unroll 1
             for (uint32_t i = t0; i < t1; ++i) {
                 ++nblocks;
                 wcnt = __builtin_amdgcn_readfirstlane(wcnt);
                 const uint32_t bpx = bp;
                 const bool inner = bpx * 32u >= ra_max && bpx * 32u + 32u <= rb_min;
-                const uint32_t inext = i + 1u < t1 ? i + 1u : i;  // (last tile of the stage: re-read this one, unused)
-                tile_body(bpx, inner, inext);
+                const bool more = i + 1u < t1;  // (last tile of the stage: re-read this one, unused)
+                slot += more ? 1u : 0u;
+                asm volatile("" : "+s"(slot));  // (otherwise the compiler re-derives it from i: ~8 scalar instructions per tile)
+                tile_body(bpx, inner, more ? i + 1u : i, slot);
             }
         }
         stage_barrier();
