@@ -852,13 +852,40 @@ int resolve_overflow(hvs_ctx* c)
     return HVS_OK;
 }
 
-// `after_batch(off, nqb)`: called after the kernels of each batch have been enqueued (the host pipeline of hvs_query
-// hangs its copies there); queries [q0 + off, q0 + off + nqb) are complete on the stream at that point, except for
-// overflowed ones (resolve_overflow)
-// `host_pipeline` (hvs_query): the first and the last batch of a call are small (kBatchMfma / 8), because the first batch's
-// queries and the last batch's results are the only transfers the pipeline cannot hide; the batches between share the rest evenly
-template <typename AfterBatch>
-int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, AfterBatch after_batch, bool host_pipeline = false)
+// Batch schedule of one call (sizes in queries, in order).  Resident runs and the exact engines cut the call into
+// full batches.  `host_pipeline` (hvs_query): the first batch's queries and the last batch's results are the only
+// transfers the pipeline cannot hide, so those two batches are small (kBatchMfma / 8) once the call is large enough to
+// pay for two extra batches, and the batches between share the rest evenly in whole quads of 512 queries.
+// The host pipeline of hvs_query stages its input by THIS schedule (the hooks receive the sizes), never by a guess of it.
+std::vector<uint32_t> batch_schedule(uint32_t nq, uint32_t step, bool ramp_allowed)
+{
+    std::vector<uint32_t> out;
+    const uint32_t edge = kBatchMfma / 8u;
+    const bool ramp = ramp_allowed && edge >= 1024u && nq >= 4u * edge;
+    if (!ramp) {
+        for (uint32_t off = 0; off < nq; off += step) out.push_back(std::min(step, nq - off));
+        return out;
+    }
+    out.push_back(edge);
+    uint32_t middle_left = nq - 2u * edge;
+    uint32_t middle_batches = hvs_ceil_div(middle_left, step);
+    while (middle_left) {
+        const uint32_t nqb = std::min(middle_left, hvs_ceil_div(hvs_ceil_div(middle_left, middle_batches), 512u) * 512u);
+        out.push_back(nqb);
+        middle_left -= nqb;
+        middle_batches -= 1u;
+    }
+    out.push_back(edge);
+    return out;
+}
+
+// Hooks of run_queries: `before(off, nqb)` is called before the kernels of a batch are enqueued (hvs_query makes the
+// compute stream wait for the batch's queries there: a batch never starts before its input is on the device);
+// `after(off, nqb, next_nqb)` after they have been enqueued (the host pipeline of hvs_query hangs its copies there);
+// queries [q0 + off, q0 + off + nqb) are complete on the stream at that point, except for overflowed ones
+// (resolve_overflow).
+template <typename Hooks>
+int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, Hooks hooks, bool host_pipeline = false)
 {
     if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
     if ((uint64_t)q0 + nq > c->nq) return fail(c, HVS_EINVAL, "query range outside the resident query set");
@@ -899,28 +926,17 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, A
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
-    const uint32_t step = mfma ? kBatchMfma : kBatch;
-    const uint32_t edge = kBatchMfma / 8u;
-    const bool ramp = host_pipeline && mfma && edge >= 1024u && nq >= 4u * edge;
-    uint32_t middle_left = 0, middle_batches = 0;
-    if (ramp) {
-        middle_left = nq - 2u * edge;
-        middle_batches = hvs_ceil_div(middle_left, step);
-    }
-    for (uint32_t off = 0, nqb = 0; off < nq; off += nqb) {
-        if (!ramp) {
-            nqb = std::min(step, nq - off);
-        } else if (off == 0u || nq - off <= edge) {
-            nqb = std::min(edge, nq - off);
-        } else {  // the middle: equal shares, whole quads of 512 queries
-            nqb = std::min(middle_left, hvs_ceil_div(hvs_ceil_div(middle_left, middle_batches), 512u) * 512u);
-            middle_left -= nqb;
-            middle_batches -= 1u;
-        }
-        int rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
-                      : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
+    const std::vector<uint32_t> sched = batch_schedule(nq, mfma ? kBatchMfma : kBatch, host_pipeline && mfma);
+    uint32_t off = 0;
+    for (size_t b = 0; b < sched.size(); ++b) {
+        const uint32_t nqb = sched[b];
+        int rc = hooks.before(off, nqb);
         if (rc) return rc;
-        if ((rc = after_batch(off, nqb))) return rc;
+        rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
+                  : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
+        if (rc) return rc;
+        if ((rc = hooks.after(off, nqb, b + 1 < sched.size() ? sched[b + 1] : 0u))) return rc;
+        off += nqb;
     }
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     if (mfma) {
@@ -941,7 +957,8 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, A
 // leaf (one GPU) implementations of the C ABI; the multi-GPU root dispatches to them
 // ---------------------------------------------------------------------------------------------
 struct NoHook {
-    int operator()(uint32_t, uint32_t) const { return HVS_OK; }
+    int before(uint32_t, uint32_t) const { return HVS_OK; }
+    int after(uint32_t, uint32_t, uint32_t) const { return HVS_OK; }
 };
 
 int leaf_create(hvs_ctx** out, int device)
@@ -1328,29 +1345,41 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         return HVS_OK;
     };
 
-    // The first batch's queries go in, then the engine runs batch by batch.  After the kernels of batch b have been
-    // enqueued (the GPU is busy with them): batch b+1's queries are staged and sent, the results of everything BEFORE
-    // batch b are sent out and drained, and the copy-out stream is told to wait for batch b.  The host work of a batch
-    // (two staging copies, ~0.2 s per 2^20 queries) hides under the batch's own compute.
-    const uint32_t ahead = std::max(kBatch, kBatchMfma);  // an upper bound of the engine's batch size
+    // The engine runs batch by batch on run_queries' own schedule.  Before the kernels of batch b are enqueued the
+    // compute stream is made to wait for the batch's queries (staged here if the previous batch's hook has not done so:
+    // the first batch, or a schedule that changed) -- a batch never starts before its input is on the device.  After
+    // they have been enqueued (the GPU is busy with them): batch b+1's queries are staged and sent, the results of
+    // everything BEFORE batch b are sent out and drained, and the copy-out stream is told to wait for batch b.  The
+    // host work of a batch (two staging copies, ~0.2 s per 2^20 queries) hides under the batch's own compute.
+    uint32_t staged_q = 0;  // queries [0, staged_q) are enqueued on the copy-in stream and the compute stream waits for them
     auto send_input = [&](uint32_t upto_q) -> int {
-        int r2 = stage_in_until(std::min(npieces, hvs_ceil_div(std::min(nq, upto_q), SQ)));
+        upto_q = std::min(nq, upto_q);
+        if (upto_q <= staged_q) return HVS_OK;
+        int r2 = stage_in_until(std::min(npieces, hvs_ceil_div(upto_q, SQ)));
         if (r2) return r2;
         HVS_HIP(c, hipEventRecord(c->ev_stage, c->s_in));
         HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
+        staged_q = std::min(nq, in_next * SQ);
         return HVS_OK;
     };
-    if ((rc = send_input(std::max(kBatch, kBatchMfma / 8u)))) return rc;  // (run_queries' first batch in pipeline mode)
-    auto after_batch = [&](uint32_t off, uint32_t nqb) -> int {
-        const uint32_t done_q = off + nqb;
-        int r2;
-        if (done_q < nq && (r2 = send_input(done_q + ahead))) return r2;
-        if ((r2 = copy_out_until(off / SQ))) return r2;  // whole pieces of the batches before this one
-        HVS_HIP(c, hipEventRecord(c->ev_batch, c->stream));
-        HVS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_batch, 0));
-        return HVS_OK;
+    struct Hooks {
+        decltype(send_input)& send;
+        decltype(copy_out_until)& copy_out;
+        hvs_ctx* c;
+        uint32_t nq;
+        int before(uint32_t off, uint32_t nqb) const { return send(off + nqb); }
+        int after(uint32_t off, uint32_t nqb, uint32_t next_nqb) const
+        {
+            int r2;
+            if (next_nqb && (r2 = send(off + nqb + next_nqb))) return r2;
+            if ((r2 = copy_out(off / hvs_ctx::kStageQ))) return r2;  // whole pieces of the batches before this one
+            HVS_HIP(c, hipEventRecord(c->ev_batch, c->stream));
+            HVS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_batch, 0));
+            return HVS_OK;
+        }
     };
-    if ((rc = run_queries(c, 0, nq, sample_proportion, after_batch, true))) return rc;
+    const Hooks hooks{send_input, copy_out_until, c, nq};
+    if ((rc = run_queries(c, 0, nq, sample_proportion, hooks, true))) return rc;
     if ((rc = copy_out_until(npieces))) return rc;
     while (!out_pinned && out_drained < out_enq)
         if ((rc = drain_one())) return rc;

@@ -645,6 +645,35 @@ print('SUBPROCESS-OK')
     assert "SUBPROCESS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("nq,devices", [(300_000, None), (600_000, None), ((1 << 20) + 1, None), (1_000_000, [0, 0])],
+                         ids=["300k", "600k", "2^20+1", "2x500k"])
+def test_host_path_stages_every_batch_it_runs(nq, devices):
+    """hvs_query at the DEFAULT batch size on an index-eligible D: call sizes between one staging send and a ramped
+    schedule (a leaf of an 8-GPU run of BASELINE configs[3] gets 5 x 10^5 queries) and one query past 2^20.  The resident
+    query buffer is poisoned with other queries first, so a batch that runs before its input was staged cannot compare
+    equal by accident; all ids must equal the resident path's."""
+    n = 40_000
+    nodes = T.gen_data(n, 61, T.GEN_V1, 20)
+    queries = T.gen_queries(nq, 62, T.GEN_V1, 20)
+    poison = T.gen_queries(nq, 63, T.GEN_V1, 20)
+    with (PKG.Engine(devices=devices) if devices else PKG.Engine(0)) as e:
+        e.load_data(nodes)
+        e.upload_queries(queries)
+        e.query_resident(0, nq, 1.0)
+        e.sync()
+        want = e.download_results(0, nq, want_dists=False)
+        assert e.last_timing().engine in FILTER_ENGINES
+        e.upload_queries(poison)                  # the device-side query buffer now holds other rows
+        got = np.full((nq, 100), 0xDEADBEEF, np.uint32)
+        e.query(queries, 1.0, want_dists=False, out_ids=got)
+        assert e.last_timing().nq == nq
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, "first wrong query %d of %d wrong" % (bad[0], bad.size)
+    sel = np.r_[0:16, 262140:262160, nq - 16:nq]
+    ref, _ = T.oracle_query(nodes, queries[sel])
+    T.check_parity(nodes, queries[sel], want[sel], ref)
+
+
 def test_config3_host_path_4e6_queries_one_call():
     """BASELINE configs[3], one GPU's view of it: D = 10^7, the whole 4 x 10^6-query set handed to hvs_query as ONE
     call from host memory (reference scope src/test.cpp:82-88: host RAM in, host RAM out), ids identical to the
