@@ -122,7 +122,7 @@ def main():
 
     for b in range(a.warmup):
         step(b)
-    kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback, untimed = 0.0, 0, 0, 0, 0.0, 0, 0, 0
+    kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback, untimed, retried = 0.0, 0, 0, 0, 0.0, 0, 0, 0, 0
     fence()
     t0 = time.perf_counter()
     for b in range(a.warmup, total_batches):
@@ -136,6 +136,7 @@ def main():
         rescored += tm.rescored_pairs
         fallback += tm.fallback_queries
         untimed += tm.untimed_launches
+        retried += tm.retry_queries
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -204,7 +205,7 @@ def main():
                          "measured_loop_ceiling_random_operands_tflops": {2: 1592.0, 3: 3350.0}.get(engine_id),
                          # bare in-place chains of the same instruction, 2 waves/SIMD (scripts/mfma_shape_lab.hip part 3)
                          "measured_bare_chain_ceiling_random_operands_tflops": {3: 4010.0}.get(engine_id),
-                         "fallback_queries": fallback},
+                         "fallback_queries": fallback, "retry_queries": retried},
             "load_s": load_s,
         }
 

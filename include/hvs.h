@@ -61,7 +61,11 @@ typedef struct hvs_timing {
                                   main_kernel_ms is then a lower bound and must not feed a roofline                    */
     double host_ms;       /* last hvs_query: wall time of the whole call, host memory in -> host memory out (the
                              reference's timing scope, src/test.cpp:82-88); 0 for the device-resident calls          */
+    uint32_t retry_queries;    /* filter engines: queries whose guessed threshold failed its check and that were run
+                                  again with a proven one (same answers either way)                                     */
+    uint32_t flags;            /* HVS_TIMING_* bits                                                                     */
 } hvs_timing;
+#define HVS_TIMING_INDEX_TOO_LARGE 1u /* the data set has more than 2^27 rows per GPU: no filter index, exact engine only */
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 

@@ -76,6 +76,7 @@ struct hvs_ctx {
     bool i8_usable = false;
     bool i8_rejected = false;  // the INT8 tiles were built and their bound was unusable: do not try again
     double index_ms = 0.0;
+    bool index_too_large = false;  // more than 2^27 rows: no filter index (hvs_timing.flags says so)
     // ... and per-batch state
     HvsBatch fb{};
     uint32_t fb_slots_cap = 0;
@@ -87,8 +88,10 @@ struct hvs_ctx {
     uint32_t quads_cap = 0, segs_cap = 0;
     HvsSegs segs{};  // of the current batch
     int num_cus = 256;
-    uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
-    uint32_t fallback_queries = 0;
+    uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;      // queries for the exact engine; d_ovf_count[0..1] = exact, retry
+    uint32_t* d_retry_list = nullptr;                            // queries whose guessed threshold was not verified
+    uint32_t fallback_queries = 0, retry_queries = 0;
+
     uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
 
     hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;
@@ -101,9 +104,10 @@ struct hvs_ctx {
     hvs_timing timing{};
     double host_ms = 0.0;     // wall time of the last hvs_query (host memory in -> host memory out)
 
-    // queries whose candidate lists overflowed, collected over all batches of a call; the exact engine re-runs them
-    // when the call's results are first needed (resolve_overflow) -- no host synchronisation inside a batch
-    uint32_t* h_ovf = nullptr;  // pinned
+    // queries whose candidate lists overflowed (-> exact engine) or whose guessed threshold failed its check (-> a filter
+    // batch with a proven last threshold), collected over all batches of a call; they are re-run when the call's results
+    // are first needed (resolve_overflow) -- no host synchronisation inside a batch
+    uint32_t* h_ovf = nullptr;  // pinned: [0] exact, [1] retry
     bool ovf_pending = false;
     uint32_t pend_sn = 0;
 
@@ -146,6 +150,16 @@ const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
 // INT8 tiles are built for v_mfma_i32_16x16x64_i8 (HVS_FMT_I8X16: 1.16x the pair rate of the 32x32x32 shape in the
 // filter loop, scripts/mfma_shape_lab.hip); HVS_I8_SHAPE=32 selects the 32x32x32 layout (HVS_FMT_I8) for A/B runs
 const int kI8Fmt = env_u32("HVS_I8_SHAPE", 16u, 16u, 32u) == 32u ? HVS_FMT_I8 : HVS_FMT_I8X16;
+// Level radices of the index (powers of two; see "Guessed thresholds" at hvs_k_merge): HVS_GUESS=0 restores round 2's
+// doubling levels with proven thresholds for A/B runs
+const bool kGuess = env_u32("HVS_GUESS", 1u, 0u, 1u) != 0u;
+uint32_t pow2_floor(uint32_t x) { uint32_t p = 2u; while (p * 2u <= x) p *= 2u; return p; }
+const uint32_t kRadixLast = kGuess ? pow2_floor(env_u32("HVS_RADIX_LAST", HVS_RADIX_LAST, 2u, 64u)) : 2u;
+const uint32_t kRadixMid = kGuess ? pow2_floor(env_u32("HVS_RADIX_MID", HVS_RADIX_MID, 2u, 64u)) : 2u;
+// order statistic of the guessed threshold at the levels before the last, and -log10 of the chance that a last level's
+// guess leaves fewer than k rows below it (plan_guess)
+const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 12u, 1u, 256u);
+const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 5u, 1u, 12u);
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
 
@@ -228,6 +242,7 @@ int ensure_results(hvs_ctx* c, uint32_t nq)
     if ((rc = dev_alloc(c, &c->d_out_ids, (size_t)nq * c->k))) return rc;
     if ((rc = dev_alloc(c, &c->d_out_dists, (size_t)nq * c->k))) return rc;
     if ((rc = dev_alloc(c, &c->d_ovf_list, (size_t)nq))) return rc;
+    if ((rc = dev_alloc(c, &c->d_retry_list, (size_t)nq))) return rc;
     c->res_cap = nq;
     return HVS_OK;
 }
@@ -487,11 +502,12 @@ int build_index(hvs_ctx* c)
 {
     free_index(c);
     const uint32_t n = c->n;
-    const HvsLevels L = hvs_make_levels(n);
+    const HvsLevels L = hvs_make_levels(n, kRadixLast, kRadixMid);
     if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
     // survivor entries carry the block position in 22 bits: above 2^27 rows per GPU the exact engine answers
     // (such a data set is sharded over GPUs anyway: 2^27 rows are 54.8 GB of rows + 35 GB of INT8 index)
-    if (L.nblk > HVS_ENTRY_MAX_BLOCKS) return HVS_OK;
+    c->index_too_large = L.nblk > HVS_ENTRY_MAX_BLOCKS;
+    if (c->index_too_large) return HVS_OK;
     c->lv = L;
     int rc;
     uint64_t *k_ct = nullptr, *k_t = nullptr;
@@ -615,7 +631,8 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
 
 // slot layout, position ranges, norms and B fragments of one batch (shared by the MFMA engine and the
 // range-based exact engine)
-int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt, bool host_counts = false)
+int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt, bool host_counts = false,
+               const uint32_t* list = nullptr)
 {
     int rc = ensure_filter_workspace(c, nqb);
     if (rc) return rc;
@@ -626,7 +643,7 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt,
     // populations stay on the device (hvs_k_query_keys2 reads them there); only the range-scan exact engine, whose
     // launch shapes depend on them, waits for a copy (`host_counts`).
     HVS_HIP(c, hipMemsetAsync(c->d_layout + 8, 0, 8 * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(hvs_k_count_classes, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb,
+    hipLaunchKernelGGL(hvs_k_count_classes, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, list,
                        c->d_layout + 8);
     if (host_counts) {
         uint32_t counts[5] = {0, 0, 0, 0, 0};
@@ -634,7 +651,7 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt,
         HVS_HIP(c, hipStreamSynchronize(c->stream));
         for (int k = 0; k < 5; ++k) c->class_counts[k] = counts[k];
     }
-    hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, c->d_keys_ct,
+    hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, list, c->d_keys_ct,
                        c->d_keys_t, n, c->d_layout + 8, c->d_keys, c->d_qidx);
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
@@ -749,17 +766,57 @@ int build_items(hvs_ctx* c)
     return HVS_OK;
 }
 
-int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
+// Order statistics of the guessed thresholds (see "Guessed thresholds" at hvs_k_merge): m[j] is used by the merge in
+// front of level j (1..K).  The rows seen before a level of radix r are a fraction f = 1/r of the rows seen after it;
+// if they were a random sample, the number X of the level's rows below the sample's m-th smallest distance would be
+// negative binomial, P(X = x) = C(x + m - 1, x) f^m (1 - f)^x, and the guess fails iff X + m < k.  Last level: the
+// smallest m with P(X <= k - m - 1) <= 10^-kGuessPfail (`proven_last`: m = k, which cannot fail).  Levels before it: any
+// m is safe -- kGuessMid, raised so that the level leaves about twice the next level's m below its threshold.
+struct GuessPlan {
+    uint32_t m[17];
+};
+GuessPlan plan_guess(const HvsLevels& L, uint32_t k, bool proven_last)
+{
+    GuessPlan G{};
+    for (uint32_t j = 0; j < 17u; ++j) G.m[j] = k;
+    if (!kGuess || L.K == 0u) return G;
+    const double target = std::pow(10.0, -(double)kGuessPfail);
+    {
+        const double f = 1.0 / (double)L.radix[L.K];
+        uint32_t m = 1;
+        for (; m < k && !proven_last; ++m) {
+            double p = std::pow(f, (double)m), cdf = 0.0;
+            for (uint32_t x = 0; x + m < k; ++x) {
+                cdf += p;
+                p *= (double)(x + m) / (double)(x + 1u) * (1.0 - f);
+            }
+            if (cdf <= target) break;
+        }
+        G.m[L.K] = proven_last ? k : std::min(m, k);
+    }
+    for (uint32_t j = L.K; j-- > 1u;) {
+        const uint32_t mid = proven_last ? std::max(kGuessMid, 32u) : kGuessMid;
+        const uint32_t feed = hvs_ceil_div(2u * G.m[j + 1u], L.radix[j]);
+        G.m[j] = std::min(k, std::max(mid, feed));
+    }
+    return G;
+}
+
+// One batch through the filter engine: the resident range [q0, q0 + nqb), or the nqb query indices in the device array
+// `list` (retry batches: `proven_last`, failures go to the exact engine).
+int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list = nullptr, bool proven_last = false)
 {
     const int fmt = c->tile_fmt;
-    int rc = prep_batch(c, q0, nqb, sn == c->n, fmt);
+    int rc = prep_batch(c, q0, nqb, sn == c->n && !list, fmt, false, list);
     if (rc) return rc;
     if ((rc = build_items(c))) return rc;
     HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
     HvsItems W{c->d_items, c->d_lvloff, c->d_cursor, HVS_SEG};
     const uint32_t n = c->n;
-    if (sn != n)
+    const GuessPlan G = plan_guess(L, c->k, proven_last || !kGuess);
+    B.fail_code = (kGuess && !proven_last) ? HVS_FAIL_RETRY : HVS_FAIL_EXACT;
+    if (sn != n && !list)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
                            c->d_counters);
 
@@ -773,34 +830,31 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
                            c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
                            std::max(1u, seed_chunks));
     });
-    auto launch_merge = [&](bool final) {
+    // merge behind a level: top-k, and the threshold of level `next` (its order statistic from the guess plan)
+    auto launch_merge = [&](bool final, uint32_t next) {
+        const uint32_t m_next = G.m[next <= 16u ? next : 16u];
         with_cap(c->cap, [&](auto CAPT) {
             constexpr int CAP = decltype(CAPT)::value;
             if (final)
                 hipLaunchKernelGGL((hvs_k_merge<true, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, m_next);
             else
                 hipLaunchKernelGGL((hvs_k_merge<false, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant);
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, m_next);
         });
     };
-    launch_merge(L.K == 0u);
+    launch_merge(L.K == 0u, 1u);
     // re-scoring blocks per group: each block stages the group's 128 queries in LDS first, so large batches use
     // few long-lived blocks per group (2: -4 % of the step at 262144 queries) and small batches enough blocks to
     // fill the chip
     const uint32_t rescore_blocks = kRescoreBlocks ? kRescoreBlocks : std::max(2u, std::min(8u, hvs_ceil_div(4096u, B.ngroups)));
-    // One re-score/merge round per level.  (Sharing a round between 2 consecutive levels was measured on
-    // D=1e6 x 1e4 queries: fewer launches but 3x the candidates per round -- slower, 0.93 vs 1.01 M q/s.)
-    const uint32_t lstep = 1u;
-    for (uint32_t level0 = 1; level0 <= L.K; level0 += lstep) {
-        const uint32_t level1 = std::min(L.K, level0 + lstep - 1u);
+    // One filter -> re-score -> merge round per level.
+    for (uint32_t level = 1; level <= L.K; ++level) {
         HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
-        for (uint32_t level = level0; level <= level1; ++level) {
-            const uint32_t count = L.off[level + 1] - L.off[level];
+        {
             const int ev = kernel_timer_begin(c);
             // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
             const dim3 fgrid(4u * (uint32_t)c->num_cus);
-            (void)count;
             W.segsize = c->segs.seg[level];
             if (fmt == HVS_FMT_I8X16)
                 hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,
@@ -819,35 +873,50 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
         else
             hipLaunchKernelGGL(hvs_k_rescore<false>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
                                sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_counters);
-        launch_merge(level1 == L.K);
+        launch_merge(level == L.K, level + 1u);
     }
-    // queries whose candidate lists overflowed go on the call's list; the exact engine answers them again when the
-    // call's results are first needed (resolve_overflow) -- the batch itself never waits for the host
+    // queries this batch could not answer go on the call's lists (retry with a proven threshold / exact engine); they
+    // are answered again when the call's results are first needed (resolve_overflow) -- the batch never waits for the host
     hipLaunchKernelGGL(hvs_k_collect_overflow, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, B, c->d_ovf_list,
-                       c->d_ovf_count);
+                       c->d_ovf_count, c->d_retry_list, c->d_ovf_count + 1);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
 
-// The exact engine re-runs the queries whose filter lists overflowed (rare: thousands of equal distances, queries
-// outside the data's bounding box, non-finite components).  Called wherever a call's results or timing leave the
-// library; costs one stream synchronisation per call.
+// Queries the call's batches could not answer.  First the retry list (a guessed threshold that failed its check, or a list
+// that overflowed under it): filter batches whose last level uses the proven threshold; what fails there joins the
+// exact list.  Then the exact engine re-runs the exact list (rare: thousands of equal distances, queries far outside the
+// data's bounding box, non-finite components).  Called wherever a call's results or timing leave the library; costs
+// one stream synchronisation per call (two more when there is something to re-run).
 int resolve_overflow(hvs_ctx* c)
 {
     if (!c->ovf_pending) return HVS_OK;
     HVS_HIP(c, hipSetDevice(c->device));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->ovf_pending = false;
-    const uint32_t novf = *c->h_ovf;
-    if (novf == 0u) return HVS_OK;
+    uint32_t novf = c->h_ovf[0];
+    const uint32_t nretry = c->h_ovf[1];
+    if (novf == 0u && nretry == 0u) return HVS_OK;
+    if (nretry) {
+        c->retry_queries = nretry;
+        for (uint32_t off = 0; off < nretry; off += kBatchMfma) {
+            const uint32_t m = std::min(kBatchMfma, nretry - off);
+            int rc = run_batch_mfma(c, 0, m, c->pend_sn, c->d_retry_list + off, true);
+            if (rc) return rc;
+        }
+        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        novf = c->h_ovf[0];
+    }
     c->fallback_queries = novf;
     c->timing.fallback_queries = novf;
+    c->timing.retry_queries = nretry;
     for (uint32_t off = 0; off < novf; off += kBatch) {
         const uint32_t m = std::min(kBatch, novf - off);
         int rc = run_batch_exact(c, 0, m, c->pend_sn, c->d_ovf_list + off, false, false);
         if (rc) return rc;
     }
-    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));  // the fallback belongs to the call's device time
+    HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));  // the re-runs belong to the call's device time
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     return HVS_OK;
 }
@@ -922,8 +991,9 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     c->n_launch_events = 0;
     c->untimed_launches = 0;
     c->fallback_queries = 0;
+    c->retry_queries = 0;
     HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+    HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
     const std::vector<uint32_t> sched = batch_schedule(nq, mfma ? kBatchMfma : kBatch, host_pipeline && mfma);
@@ -940,7 +1010,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     }
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     if (mfma) {
-        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         c->ovf_pending = true;
         c->pend_sn = sn;
     }
@@ -949,6 +1019,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     c->timing.engine = mfma ? (HVS_IS_I8(c->tile_fmt) ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
     c->timing.n_gpus = 1;
+    c->timing.flags = c->index_too_large ? HVS_TIMING_INDEX_TOO_LARGE : 0u;
     c->timing_valid = true;
     return HVS_OK;
 }
@@ -1007,11 +1078,11 @@ int leaf_create(hvs_ctx** out, int device)
     }
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_layout), 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ovf), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ovf), 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
-    *c->h_ovf = 0u;
+    c->h_ovf[0] = c->h_ovf[1] = 0u;
     *out = c;
     return HVS_OK;
 }
@@ -1031,7 +1102,7 @@ void leaf_destroy(hvs_ctx* c)
         HvsBatch& B = c->fb;
         void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
                       B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
-                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count,
+                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count, c->d_retry_list,
                       c->d_qlo, c->d_qhi, c->d_segcnt, c->d_segoff, c->d_lvloff, c->d_cursor, c->d_items};
         for (void* p : fp)
             if (p) (void)hipFree(p);
@@ -1387,10 +1458,12 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
     // overflowed queries: re-run by the exact engine, their rows fetched again
     const bool had_ovf = c->ovf_pending;
     if ((rc = resolve_overflow(c))) return rc;
-    if (had_ovf && c->fallback_queries) {
-        const uint32_t novf = c->fallback_queries;
-        std::vector<uint32_t> list(novf);
-        HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (had_ovf && (c->fallback_queries || c->retry_queries)) {
+        const uint32_t novf = c->fallback_queries, nretry = c->retry_queries;
+        std::vector<uint32_t> list((size_t)novf + nretry);
+        if (novf) HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (nretry)
+            HVS_HIP(c, hipMemcpy(list.data() + novf, c->d_retry_list, (size_t)nretry * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t qi : list) {
             HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * c->k, c->d_out_ids + (size_t)qi * c->k, c->k * sizeof(uint32_t),
                                       hipMemcpyDeviceToHost, c->stream));
@@ -1426,6 +1499,7 @@ int leaf_last_timing(hvs_ctx* c, hvs_timing* out)
     c->timing.scanned_pairs = h[1];
     c->timing.rescored_pairs = h[2];
     c->timing.fallback_queries = c->fallback_queries;
+    c->timing.retry_queries = c->retry_queries;
     c->timing.untimed_launches = c->untimed_launches;
     c->timing.host_ms = c->host_ms;
     *out = c->timing;
@@ -1893,6 +1967,8 @@ int hvs_last_timing(hvs_ctx* c, hvs_timing* out)
         agg.scanned_pairs += t.scanned_pairs;
         agg.rescored_pairs += t.rescored_pairs;
         agg.fallback_queries += t.fallback_queries;
+        agg.retry_queries += t.retry_queries;
+        agg.flags |= t.flags;
         agg.untimed_launches += t.untimed_launches;
         agg.load_ms = std::max(agg.load_ms, t.load_ms);
         agg.engine = t.engine;

@@ -180,7 +180,8 @@ __device__ __forceinline__ uint32_t hvs_prefix_count(uint64_t mask)
 // bucket.  Distances of one query's candidates separate within ~3 digits below their common prefix, against
 // ~25 single-bit steps of 4 ballots each: the merge kernels spend 5-6x fewer instructions here.
 // NK = keys per lane: the list holds at most 64 NK keys (256 for k <= 128, 512 for k <= 256); `keep` = k at run time.
-template <int NK>
+// COMPACT = false: only the keep-th smallest key is returned, the list is left as it is.
+template <int NK, bool COMPACT = true>
 __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32_t cnt, uint32_t keep, uint32_t lane, uint32_t* hist)
 {
     uint64_t k[NK];
@@ -264,6 +265,7 @@ __device__ __forceinline__ uint64_t hvs_wave_select_prune(uint64_t* list, uint32
         if (lo == 0) break;  // every bit decided: prefix is the key
         hi = lo - 1;
     }
+    if constexpr (!COMPACT) return prefix;
     uint32_t base = 0;
 #pragma unroll
     for (int i = 0; i < NK; ++i) {

@@ -41,7 +41,7 @@
 #endif
 #define HVS_GROUP (32 * HVS_QB)
 #define HVS_FCAP 1024         // per-query candidate keys per round
-#define HVS_GCAP (HVS_GROUP * 768)  // per-group (query,pos) pairs per round
+#define HVS_GCAP (HVS_GROUP * 1024) // per-group survivor entries per round
 #ifndef HVS_SEG
 #define HVS_SEG 256           // row blocks per filter work item (128: -1 % mixed, -2.7 % type-0: twice the item prologues)
 #endif
@@ -51,8 +51,11 @@
 #ifndef HVS_STAGE_I8
 #define HVS_STAGE_I8 8        // the same for INT8 tiles (4 KiB): 2 x 33 KiB of LDS per workgroup
 #endif
-#ifndef HVS_RADIX2_LEVELS
-#define HVS_RADIX2_LEVELS 14u  // how many of the last levels double (rather than quadruple) the rows seen (all)
+#ifndef HVS_RADIX_LAST
+#define HVS_RADIX_LAST 4u      // the last level multiplies the rows a query has seen by this (a power of two) ...
+#endif
+#ifndef HVS_RADIX_MID
+#define HVS_RADIX_MID 16u      // ... and every level before it by this (see "Guessed thresholds" at hvs_k_merge)
 #endif
 #ifndef HVS_WG_WAVES
 #define HVS_WG_WAVES 4        // waves (= query groups) per filter workgroup sharing one tile stream
@@ -139,7 +142,8 @@ struct HvsLevels {
     uint32_t off[16];       // storage offset of each level; off[K+1] = nblk
     uint32_t stride[16];    // level j holds the multiples of stride[j] ...
     uint32_t radix[16];     // ... that are not multiples of stride[j-1] = stride[j] * radix[j]  (j >= 1)
-    uint32_t shift[16];     // log2(stride[j]) when every radix is 2 (pow2 != 0): the runs then need no division
+    uint32_t shift[16];     // log2(stride[j]) and
+    uint32_t rshift[16];    // log2(radix[j]) when strides and radices are powers of two (pow2 != 0): the runs need no division
     uint32_t pow2;
 };
 
@@ -156,11 +160,11 @@ __host__ __device__ static inline void hvs_level_run(const HvsLevels& L, uint32_
         return;
     }
     const uint32_t s = L.stride[j];
-    if (L.pow2) {  // radix 2 everywhere (the default): shifts; #{u in [0,t) : u odd} = t >> 1
-        const uint32_t sh = L.shift[j];
+    if (L.pow2) {  // power-of-two radices (the default tables): shifts; #{u in [0,t) : u % r != 0} = t - ceil(t / r)
+        const uint32_t sh = L.shift[j], rs = L.rshift[j], r1 = (1u << rs) - 1u;
         const uint32_t tlo = (blo + s - 1u) >> sh, thi = (bhi + s - 1u) >> sh;
-        lo = L.off[j] + (j == 0 ? tlo : (tlo >> 1));
-        hi = L.off[j] + (j == 0 ? thi : (thi >> 1));
+        lo = L.off[j] + (j == 0 ? tlo : tlo - ((tlo + r1) >> rs));
+        hi = L.off[j] + (j == 0 ? thi : thi - ((thi + r1) >> rs));
         return;
     }
     const uint32_t tlo = hvs_ceil_div(blo, s), thi = hvs_ceil_div(bhi, s);
@@ -183,17 +187,19 @@ __host__ __device__ static inline uint32_t hvs_storage_to_block(const HvsLevels&
     return (i + i / (L.radix[j] - 1u) + 1u) * L.stride[j];  // the i-th positive integer that is not a multiple of radix
 }
 
-// level table of an ordering with n rows (host)
-static inline HvsLevels hvs_make_levels(uint32_t n)
+// level table of an ordering with n rows (host).  Radices (powers of two) from the last level backwards: r_last, then
+// r_mid, ..., each cut down so that level 0 keeps >= 16 blocks (512 rows): n = 10^7 -> level 0 of 19 blocks, then
+// radices 16, 16, 16, 4.  r_last = r_mid = 2 gives round 2's doubling levels (up to 14 of them).
+static inline HvsLevels hvs_make_levels(uint32_t n, uint32_t r_last = HVS_RADIX_LAST, uint32_t r_mid = HVS_RADIX_MID)
 {
     HvsLevels L{};
     L.nblk = (n + 31u) / 32u;
-    // radices from the last level backwards: 2, 2, 2, then 4s, while level 0 keeps >= 16 blocks (512 rows)
     uint32_t rad[16];
     uint32_t K = 0, S = 1;
     for (;;) {
-        const uint32_t r = K < HVS_RADIX2_LEVELS ? 2u : 4u;
-        if (K >= 14u || L.nblk / (S * r) < 16u) break;
+        uint32_t r = K == 0 ? r_last : r_mid;
+        while (r >= 2u && (uint64_t)L.nblk / ((uint64_t)S * r) < 16u) r >>= 1;
+        if (r < 2u || K >= 14u) break;
         rad[K++] = r;
         S *= r;
     }
@@ -217,10 +223,12 @@ static inline HvsLevels hvs_make_levels(uint32_t n)
     }
     L.pow2 = 1u;
     for (uint32_t j = 0; j < 16u; ++j) {
-        uint32_t sh = 0;
+        uint32_t sh = 0, rs = 0;
         while ((1u << sh) < L.stride[j]) ++sh;
+        while ((1u << rs) < L.radix[j]) ++rs;
         L.shift[j] = sh;
-        if ((1u << sh) != L.stride[j] || (j >= 1u && j <= K && L.radix[j] != 2u)) L.pow2 = 0u;
+        L.rshift[j] = rs;
+        if ((1u << sh) != L.stride[j] || (1u << rs) != L.radix[j]) L.pow2 = 0u;
     }
     return L;
 }
@@ -601,12 +609,23 @@ struct HvsBatch {
     float* tau;                 // [nslots]
     uint64_t* cand;             // [nslots][HVS_FCAP]
     uint32_t* candcnt;          // [nslots]
-    uint32_t* overflow;         // [nslots]
+    uint32_t* overflow;         // [nslots] 0 = answered; HVS_FAIL_RETRY: run again with proven thresholds; HVS_FAIL_EXACT: exact engine
+    uint32_t fail_code;         // what a capacity overflow / failed verification of THIS batch writes there (see hvs_flag_fail)
     // filter output
     uint64_t* pairs;            // [ngroups][HVS_GCAP]  survivor entries (hvs_entry_make)
     uint32_t* paircnt;          // [ngroups]
     uint32_t* goverflow;        // [ngroups]
 };
+
+// A query the filter engine cannot answer in this batch.  HVS_FAIL_RETRY (batches with guessed thresholds): the query is
+// run again in a batch whose last level uses a proven threshold; HVS_FAIL_EXACT (queries without a usable bound, and any
+// failure inside such a retry batch): the exact engine answers it.  The larger code wins.
+#define HVS_FAIL_RETRY 1u
+#define HVS_FAIL_EXACT 2u
+__device__ __forceinline__ void hvs_flag_fail(const uint32_t code, uint32_t* __restrict__ overflow, uint32_t slot)
+{
+    if (overflow[slot] < code) overflow[slot] = code;  // (racing writers of one batch all write the same code)
+}
 
 // Survivor entry of the filter (8 bytes in the group's pair list): the lanes of one (tile, query block) whose
 // accumulators reached the threshold.  bits 0..15 accumulator mask (bit r = row (r & 3) + 8 (r >> 2) + 4 half of
@@ -690,11 +709,13 @@ __device__ __forceinline__ void hvs_query_range(const HvsQParams& p, const uint6
 // the union range the wave has to stream is close to each query's own range.
 
 // population of each predicate class in the batch (sizes the start-position bins)
-__global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, uint32_t nq, uint32_t* __restrict__ counts)
+// (`list`: the batch is the nq query indices stored there instead of the range [q0, q0 + nq) -- retry batches)
+__global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, uint32_t nq, const uint32_t* __restrict__ list,
+                                    uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t rank = 0xFFu;
-    if (i < nq) rank = hvs_type_rank(hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS).type);
+    if (i < nq) rank = hvs_type_rank(hvs_parse_query(Q + (size_t)(list ? list[i] : q0 + i) * HVS_QCOLS).type);
     // one atomic per wave and class (one per query serialises 262144 atomics on 5 addresses: 1.4 ms)
 #pragma unroll
     for (uint32_t k = 0; k < 5u; ++k) {
@@ -711,13 +732,14 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
 #endif
 // `counts`: the batch's class populations (hvs_k_count_classes) -- read on the device, so that forming a batch needs
 // no host round trip
-__global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq,
+__global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq, const uint32_t* __restrict__ list,
                                   const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
                                   const uint32_t* __restrict__ counts, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
-    const HvsQParams p = hvs_parse_query(Q + (size_t)(q0 + i) * HVS_QCOLS);
+    const uint32_t qi = list ? list[i] : q0 + i;
+    const HvsQParams p = hvs_parse_query(Q + (size_t)qi * HVS_QCOLS);
     const uint32_t rk = hvs_type_rank(p.type);
     uint32_t a, b;
     hvs_query_range(p, keys_ct, keys_t, n, a, b);
@@ -731,7 +753,7 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     nbins = nbins < 1u ? 1u : (nbins > 4096u ? 4096u : nbins);
     const uint32_t abin = (uint32_t)(((uint64_t)a * nbins) / ((uint64_t)n + 1ull));
     keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
-    idx[i] = q0 + i;
+    idx[i] = qi;
 }
 
 // Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole quad of
@@ -828,7 +850,7 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
     B.topcnt[s] = 0;
     B.candcnt[s] = 0;
     // a query with non-finite components has no usable bound: it is answered by the exact engine
-    B.overflow[s] = (qi != 0xFFFFFFFFu && (clipped || !(qn < 1.0e30))) ? 1u : 0u;
+    B.overflow[s] = (qi != 0xFFFFFFFFu && (clipped || !(qn < 1.0e30))) ? HVS_FAIL_EXACT : 0u;
     B.tau[s] = __builtin_inff();
     // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
     if (HVS_IS_I8(fmt))
@@ -1015,7 +1037,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
                     if (k < HVS_FCAP)
                         mylist[k] = hvs_make_key(dist, id);
                     else
-                        B.overflow[slot] = 1u;
+                        hvs_flag_fail(B.fail_code, B.overflow, slot);
                 }
                 continue;
             }
@@ -2107,7 +2129,7 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     // them are used, all of its queries are re-run by the exact engine
     if (np > HVS_GCAP || B.goverflow[g]) np = 0;
     if (blockIdx.x == 0u && threadIdx.x == 0u && B.goverflow[g]) {
-        for (uint32_t s = 0; s < HVS_GROUP; ++s) B.overflow[g * HVS_GROUP + s] = 1u;
+        for (uint32_t s = 0; s < HVS_GROUP; ++s) hvs_flag_fail(B.fail_code, B.overflow, g * HVS_GROUP + s);
     }
     if (blockIdx.x * (64u * HVS_RESCORE_WAVES) >= np) return;  // uniform over the block
     for (uint32_t e = threadIdx.x; e < HVS_GROUP * (HVS_NDIM / 4); e += blockDim.x) {
@@ -2151,7 +2173,7 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
                 if (pend_k[u] < HVS_FCAP)
                     B.cand[(size_t)pend_slot[u] * HVS_FCAP + pend_k[u]] = pend_key[u];
                 else
-                    B.overflow[pend_slot[u]] = 1u;
+                    hvs_flag_fail(B.fail_code, B.overflow, pend_slot[u]);
             }
             pend[u] = false;
         }
@@ -2265,9 +2287,28 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// hvs_k_merge -- per slot (one wave): top-100 := 100 smallest keys of (top U cand); new tau and
-// the filter threshold theta for the next level.  With `final` it also pads from the end of D
+// hvs_k_merge -- per slot (one wave): top-k := k smallest keys of (top U cand); the threshold tau of the NEXT level
+// and the filter threshold theta that belongs to it.  With `final` it verifies the answer, pads from the end of D
 // (optimized_parallel.hpp:149-157), rank-sorts and writes the answer at the query's own index.
+//
+// Guessed thresholds.  A level multiplies the rows a query has seen by its radix r.  With the PROVEN threshold (tau =
+// the k-th smallest distance seen so far, what the reference's Knn::check_add compares against, optimized_impl.h:301)
+// the level hands k (r - 1) rows to the exact kernel -- which is why round 2 doubled (r = 2, 14 levels, ~k rows per
+// query and level).  The rows seen so far are a systematic sample (every r-th block) of the rows seen after the level,
+// so the k-th smallest distance AFTER the level is close to the (k / r)-th smallest BEFORE it.  The merge in front of a
+// level therefore sets
+//     tau_next = min(tau_now, m-th smallest distance held)            (m = m_next <= k; unchanged while fewer are held)
+// with m chosen on the host (hvs.hip, plan_guess): for the levels before the last any small m will do (m = 12: the
+// level then hands ~ m r = 190 rows to the exact kernel whatever k is), for the last level the smallest m whose
+// chance of leaving fewer than k rows below tau is under the target (k = 100, r = 4: m = 46 for 10^-5 -- ~140 rows
+// instead of 300).  Nothing is taken on trust:
+//   * tau only ever decreases, every row with exact distance <= tau of its level reaches the exact kernel (the filter's
+//     bound, see theta below) and the top-k truncation only drops keys above k kept ones -- so after the last level
+//     the list holds EVERY row of the query's range with distance <= tau_last;
+//   * the final merge checks that the k-th smallest key it holds is <= tau_last (or that tau never became finite:
+//     nothing was ever discarded).  Then the k smallest keys held are the k smallest of the whole range, bit for bit
+//     what the proven threshold gives.  Otherwise the query is flagged (B.fail_code) and run again in a batch whose
+//     last level uses m = k.
 //
 // theta: a row can be discarded when its exact-order distance R is certainly > tau.
 //   R >= T (1 - g), T = |q-d|^2 (real), g = 20 * 2^-24 (f32 roundings of the reference order)
@@ -2279,12 +2320,12 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
 //      slack = 1e-9 (|q|^2 + tau + band) covering the f64 evaluation of theta itself
 // ---------------------------------------------------------------------------------------------
 // (FINAL as a template parameter: the padding path's exact-order distance costs 70 VGPRs that would halve the
-// occupancy of the 13 latency-bound merges before it)
+// occupancy of the latency-bound merges before it)
 template <bool FINAL, int CAP>
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
                                                    HvsBatch B, const HvsBounds* __restrict__ bounds, int pad,
                                                    uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, int fmt,
-                                                   const HvsQuant* __restrict__ qz)
+                                                   const HvsQuant* __restrict__ qz, uint32_t m_next)
 {
     __shared__ uint64_t sbuf[4][CAP];
     __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
@@ -2298,7 +2339,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     uint64_t* buf = sbuf[w];
     uint32_t m = B.candcnt[slot];
     if (m > HVS_FCAP) m = HVS_FCAP;
-    if (m == 0u && !FINAL) return;  // nothing new at this level: top-100, tau and theta stand
+    if (m == 0u && !FINAL) return;  // nothing new at this level: top-k, tau and theta stand
     uint32_t cnt = B.topcnt[slot];
     for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * B.topcap + e];
     const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
@@ -2319,23 +2360,34 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         cnt = knn;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
+    // largest distance held, as key bits (finite < +inf < NaN, the order of the keys)
+    uint32_t dmax_bits = 0u;
+    for (uint32_t e = lane; e < cnt; e += 64u) {
+        const uint32_t bits = (uint32_t)(buf[e] >> 32);
+        dmax_bits = bits > dmax_bits ? bits : dmax_bits;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)dmax_bits, o);
+        dmax_bits = other > dmax_bits ? other : dmax_bits;
+    }
     if constexpr (!FINAL) {
         for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * B.topcap + e] = buf[e];
-        // tau = largest kept distance once 100 are held
-        float dmax = 0.0f;
-        for (uint32_t e = lane; e < cnt; e += 64u) dmax = fmaxf(dmax, hvs_key_dist(buf[e]));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        // the m_next-th smallest distance held (the largest one when exactly m_next are held)
+        uint32_t mth_bits = dmax_bits;
+        const uint32_t mn = m_next < knn ? m_next : knn;
+        if (cnt > mn) mth_bits = (uint32_t)(hvs_wave_select_prune<CAP / 64, false>(buf, cnt, mn, lane, shist[w]) >> 32);
         if (lane == 0u) {
             B.topcnt[slot] = cnt;
             B.candcnt[slot] = 0;
-            float tau = __builtin_inff();
+            float tau = B.tau[slot];  // (+inf until the first cut)
+            if (cnt >= mn) tau = fminf(tau, __uint_as_float(mth_bits));  // (a NaN key leaves tau as it is)
+            const bool cut = tau < __builtin_inff();
             float theta = B.rb[slot] > B.ra[slot] ? -__builtin_inff() : __builtin_inff();
             if (HVS_IS_I8(fmt)) {
                 // INT8 formats (see "INT8 filter" above): S = qq.dq + nh is exact, the band has no accumulation term
                 int ti = B.rb[slot] > B.ra[slot] ? (int)0x80000000 : 0x7FFFFFFF;
-                if (cnt >= knn) {
-                    tau = dmax;
+                if (cut) {
                     const double g = 20.0 * 5.9604644775390625e-08;
                     const double iu = qz->inv_sd * qz->inv_sd;  // 1 / sd^2
                     const double band = ((double)B.nqb[slot] * (double)bounds->e_d8 + (double)B.eq[slot] * (double)bounds->n_d8) *
@@ -2352,8 +2404,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                 B.thetai[slot] = ti;
                 return;
             }
-            if (cnt >= knn) {
-                tau = dmax;
+            if (cut) {
                 const double g = 20.0 * 5.9604644775390625e-08;
                 const double sabs = (double)B.nqb[slot] * (double)bounds->nb_d + 1.02 * (double)bounds->hmax;
                 const double mu = 256.0 * 5.9604644775390625e-08 * sabs;
@@ -2374,6 +2425,13 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
             B.theta[slot] = theta;
         }
         return;
+    }
+    // ---- final: verify.  Every row of the range with distance <= tau_last is held (see "Guessed thresholds"): the k
+    // smallest keys held are the answer iff the k-th of them is <= tau_last, or nothing was ever discarded (tau = +inf).
+    if (lane == 0u) {
+        const uint32_t tau_bits = __float_as_uint(B.tau[slot]);
+        const bool verified = tau_bits == 0x7F800000u || (cnt >= knn && dmax_bits <= tau_bits);
+        if (!verified) hvs_flag_fail(B.fail_code, B.overflow, slot);
     }
     // ---- final: pad, rank-sort, write
     const float* __restrict__ qv = Q + (size_t)qi * HVS_QCOLS + 4;
@@ -2399,11 +2457,17 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     }
 }
 
-// queries whose candidate lists overflowed -> appended to the call's list for the exact engine (`count` runs over all
-// batches of a call)
-__global__ void hvs_k_collect_overflow(HvsBatch B, uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+// queries this batch did not answer -> appended to the call's lists: HVS_FAIL_EXACT for the exact engine, HVS_FAIL_RETRY
+// for a filter batch with a proven last threshold (the counts run over all batches of a call)
+__global__ void hvs_k_collect_overflow(HvsBatch B, uint32_t* __restrict__ list_exact, uint32_t* __restrict__ count_exact,
+                                       uint32_t* __restrict__ list_retry, uint32_t* __restrict__ count_retry)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B.nslots) return;
-    if (B.qid[s] != 0xFFFFFFFFu && B.overflow[s]) list[atomicAdd(count, 1u)] = B.qid[s];
+    if (B.qid[s] == 0xFFFFFFFFu) return;
+    const uint32_t code = B.overflow[s];
+    if (code >= HVS_FAIL_EXACT)
+        list_exact[atomicAdd(count_exact, 1u)] = B.qid[s];
+    else if (code == HVS_FAIL_RETRY)
+        list_retry[atomicAdd(count_retry, 1u)] = B.qid[s];
 }

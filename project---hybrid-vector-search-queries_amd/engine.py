@@ -30,7 +30,8 @@ class Timing(C.Structure):
     _fields_ = [("query_ms", C.c_double), ("main_kernel_ms", C.c_double), ("main_kernel_launches", C.c_uint32),
                 ("nq", C.c_uint32), ("pairs", C.c_uint64), ("scanned_pairs", C.c_uint64), ("load_ms", C.c_double),
                 ("engine", C.c_uint32), ("fallback_queries", C.c_uint32), ("rescored_pairs", C.c_uint64),
-                ("n_gpus", C.c_uint32), ("untimed_launches", C.c_uint32), ("host_ms", C.c_double)]
+                ("n_gpus", C.c_uint32), ("untimed_launches", C.c_uint32), ("host_ms", C.c_double),
+                ("retry_queries", C.c_uint32), ("flags", C.c_uint32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -10,8 +10,13 @@
 int main()
 {
     const uint32_t sizes[] = {100, 2047, 2048 * 32, 10000, 70000, 300001, 1000000, 10000000, 33554432};
+    const uint32_t radices[][2] = {{HVS_RADIX_LAST, HVS_RADIX_MID}, {2, 2}, {8, 16}, {16, 16}, {2, 4}, {64, 32}};  // {last, mid}
+    for (const auto& rr : radices)
     for (uint32_t n : sizes) {
-        const HvsLevels L = hvs_make_levels(n);
+        const HvsLevels L = hvs_make_levels(n, rr[0], rr[1]);
+        if (!L.pow2) { std::printf("FAIL n=%u: power-of-two radices expected\n", n); return 1; }
+        if (L.K && L.radix[L.K] > rr[0]) { std::printf("FAIL n=%u: last radix %u > %u\n", n, L.radix[L.K], rr[0]); return 1; }
+        if (L.off[1] - L.off[0] < 16u && L.nblk >= 16u) { std::printf("FAIL n=%u: level 0 has %u blocks\n", n, L.off[1] - L.off[0]); return 1; }
         if (L.off[L.K + 1] != L.nblk) { std::printf("FAIL n=%u: levels cover %u of %u blocks\n", n, L.off[L.K + 1], L.nblk); return 1; }
         std::vector<uint32_t> where(L.nblk, 0xFFFFFFFFu);
         for (uint32_t idx = 0; idx < L.nblk; ++idx) {
