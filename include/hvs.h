@@ -173,6 +173,11 @@ int hvs_merge_shards_device(hvs_ctx *ctx, uint32_t nshards, uint32_t nq, const u
                             const float *d_pad_dists, uint32_t *d_out_ids, float *d_out_dists);
 /* Timing of the last hvs_query / hvs_query_resident (call after hvs_sync). */
 int hvs_last_timing(hvs_ctx *ctx, hvs_timing *out);
+/* Diagnostics: which queries of the last call were answered a second time (call after hvs_sync / hvs_query).
+ * which = 0: the exact engine's list (hvs_timing.fallback_queries), 1: the retry list (hvs_timing.retry_queries).
+ * Copies up to cap query indices (relative to the call's resident query set) to out_idx and returns the list's length,
+ * or a negative HVS_E* code.  Single-GPU contexts only. */
+int hvs_last_reruns(hvs_ctx *ctx, int which, uint32_t *out_idx, uint32_t cap);
 
 const char *hvs_version(void);
 

@@ -91,6 +91,8 @@ struct hvs_ctx {
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;      // queries for the exact engine; d_ovf_count[0..1] = exact, retry
     uint32_t* d_retry_list = nullptr;                            // queries whose guessed threshold was not verified
     uint32_t fallback_queries = 0, retry_queries = 0;
+    HvsGuessTable guess_tab[2]{};  // order statistics of the guessed thresholds for k = guess_k: [0] batches, [1] retry batches
+    uint32_t guess_k = 0;
 
     uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
 
@@ -156,9 +158,9 @@ const bool kGuess = env_u32("HVS_GUESS", 1u, 0u, 1u) != 0u;
 uint32_t pow2_floor(uint32_t x) { uint32_t p = 2u; while (p * 2u <= x) p *= 2u; return p; }
 const uint32_t kRadixLast = kGuess ? pow2_floor(env_u32("HVS_RADIX_LAST", HVS_RADIX_LAST, 2u, 64u)) : 2u;
 const uint32_t kRadixMid = kGuess ? pow2_floor(env_u32("HVS_RADIX_MID", HVS_RADIX_MID, 2u, 64u)) : 2u;
-// order statistic of the guessed threshold at the levels before the last, and -log10 of the chance that a last level's
-// guess leaves fewer than k rows below it (plan_guess)
-const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 12u, 1u, 256u);
+// smallest order statistic a guessed threshold may use, and -log10 of the chance that one guess leaves fewer than k rows
+// below it (plan_guess)
+const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 3u, 1u, 256u);
 const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 5u, 1u, 12u);
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
@@ -766,39 +768,33 @@ int build_items(hvs_ctx* c)
     return HVS_OK;
 }
 
-// Order statistics of the guessed thresholds (see "Guessed thresholds" at hvs_k_merge): m[j] is used by the merge in
-// front of level j (1..K).  The rows seen before a level of radix r are a fraction f = 1/r of the rows seen after it;
-// if they were a random sample, the number X of the level's rows below the sample's m-th smallest distance would be
-// negative binomial, P(X = x) = C(x + m - 1, x) f^m (1 - f)^x, and the guess fails iff X + m < k.  Last level: the
-// smallest m with P(X <= k - m - 1) <= 10^-kGuessPfail (`proven_last`: m = k, which cannot fail).  Levels before it: any
-// m is safe -- kGuessMid, raised so that the level leaves about twice the next level's m below its threshold.
-struct GuessPlan {
-    uint32_t m[17];
-};
-GuessPlan plan_guess(const HvsLevels& L, uint32_t k, bool proven_last)
+// Order statistics of the guessed thresholds (see "Guessed thresholds" at hvs_k_merge).  If the rows seen so far were a
+// random sample holding a fraction F of the query's rows, the number X of unseen rows below the sample's m-th smallest
+// distance would be negative binomial, P(X = x) = C(x + m - 1, x) F^m (1 - F)^x, and a threshold at that distance leaves
+// fewer than k rows below it iff X + m < k.  guess_m: the smallest m with P(X <= k - m - 1) <= target (m = k cannot fail).
+uint32_t guess_m(double F, uint32_t k, double target)
 {
-    GuessPlan G{};
-    for (uint32_t j = 0; j < 17u; ++j) G.m[j] = k;
-    if (!kGuess || L.K == 0u) return G;
-    const double target = std::pow(10.0, -(double)kGuessPfail);
-    {
-        const double f = 1.0 / (double)L.radix[L.K];
-        uint32_t m = 1;
-        for (; m < k && !proven_last; ++m) {
-            double p = std::pow(f, (double)m), cdf = 0.0;
-            for (uint32_t x = 0; x + m < k; ++x) {
-                cdf += p;
-                p *= (double)(x + m) / (double)(x + 1u) * (1.0 - f);
-            }
-            if (cdf <= target) break;
+    if (!(F > 0.0)) return k;
+    if (F >= 1.0) return k;  // every row has been seen: only the k-th smallest itself leaves k rows below it
+    for (uint32_t m = 1; m < k; ++m) {
+        double lp = (double)m * std::log(F), cdf = 0.0;  // log P(X = 0)
+        const double l1 = std::log1p(-F);
+        for (uint32_t x = 0; x + m < k; ++x) {
+            cdf += std::exp(lp);
+            lp += std::log((double)(x + m) / (double)(x + 1u)) + l1;
         }
-        G.m[L.K] = proven_last ? k : std::min(m, k);
+        if (cdf <= target) return m;
     }
-    for (uint32_t j = L.K; j-- > 1u;) {
-        const uint32_t mid = proven_last ? std::max(kGuessMid, 32u) : kGuessMid;
-        const uint32_t feed = hvs_ceil_div(2u * G.m[j + 1u], L.radix[j]);
-        G.m[j] = std::min(k, std::max(mid, feed));
-    }
+    return k;
+}
+// `proven_last` (retry batches): the last level uses m = k and the levels before it a far smaller target
+HvsGuessTable plan_guess(uint32_t k, bool proven_last)
+{
+    HvsGuessTable G{};
+    const double target = std::pow(10.0, -(double)(proven_last ? 2u * kGuessPfail + 2u : kGuessPfail));
+    for (int i = 0; i < HVS_GUESS_STEPS; ++i) G.m[i] = (uint16_t)(kGuess ? guess_m(std::exp2(-(double)i / 8.0), k, target) : k);
+    G.floor_m = (uint16_t)std::min(k, kGuess ? kGuessMid : k);
+    G.last_m = (uint16_t)((proven_last || !kGuess) ? k : 0u);
     return G;
 }
 
@@ -814,7 +810,12 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     const HvsLevels L = c->lv;
     HvsItems W{c->d_items, c->d_lvloff, c->d_cursor, HVS_SEG};
     const uint32_t n = c->n;
-    const GuessPlan G = plan_guess(L, c->k, proven_last || !kGuess);
+    if (c->guess_k != c->k) {  // (two tables per k: 168 x ~100 negative-binomial sums, ~10 ms on the host)
+        c->guess_tab[0] = plan_guess(c->k, false);
+        c->guess_tab[1] = plan_guess(c->k, true);
+        c->guess_k = c->k;
+    }
+    const HvsGuessTable G = c->guess_tab[proven_last ? 1 : 0];
     B.fail_code = (kGuess && !proven_last) ? HVS_FAIL_RETRY : HVS_FAIL_EXACT;
     if (sn != n && !list)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
@@ -832,15 +833,14 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     });
     // merge behind a level: top-k, and the threshold of level `next` (its order statistic from the guess plan)
     auto launch_merge = [&](bool final, uint32_t next) {
-        const uint32_t m_next = G.m[next <= 16u ? next : 16u];
         with_cap(c->cap, [&](auto CAPT) {
             constexpr int CAP = decltype(CAPT)::value;
             if (final)
                 hipLaunchKernelGGL((hvs_k_merge<true, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, m_next);
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, L, next, G);
             else
                 hipLaunchKernelGGL((hvs_k_merge<false, CAP>), dim3((B.nslots + 3u) / 4u), dim3(256), 0, c->stream, c->d_data, n, c->d_q, B,
-                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, m_next);
+                                   c->d_bounds, c->padding ? 1 : 0, c->d_out_ids, c->d_out_dists, fmt, c->d_quant, L, next, G);
         });
     };
     launch_merge(L.K == 0u, 1u);
@@ -1945,6 +1945,20 @@ int hvs_merge_shards_device(hvs_ctx* c, uint32_t nshards, uint32_t nq, const uin
     });
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
+}
+
+int hvs_last_reruns(hvs_ctx* c, int which, uint32_t* out_idx, uint32_t cap)
+{
+    if (!c) return HVS_EINVAL;
+    if (!c->kids.empty()) return fail(c, HVS_EINVAL, "hvs_last_reruns: single-GPU contexts only");
+    if (which != 0 && which != 1) return fail(c, HVS_EINVAL, "hvs_last_reruns: which is 0 (exact) or 1 (retry)");
+    int rc = leaf_sync(c);
+    if (rc) return rc;
+    const uint32_t len = which ? c->retry_queries : c->fallback_queries;
+    const uint32_t m = std::min(len, cap);
+    if (m && out_idx)
+        HVS_HIP(c, hipMemcpy(out_idx, which ? c->d_retry_list : c->d_ovf_list, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return (int)len;
 }
 
 int hvs_last_timing(hvs_ctx* c, hvs_timing* out)

@@ -2286,6 +2286,55 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     if (lane == 0u && npairs) atomicAdd(&counters[2], (unsigned long long)npairs);
 }
 
+// Order statistic of a guessed threshold as a function of the fraction F of the query's rows seen so far (host:
+// plan_guess in hvs.hip): m[i] belongs to F = 2^(-i/8); a query looks up the next smaller grid value of its own F.
+#define HVS_GUESS_STEPS 168  // F down to 2^-20.9
+struct HvsGuessTable {
+    uint16_t m[HVS_GUESS_STEPS];
+    uint16_t floor_m;   // smallest order statistic used at all
+    uint16_t last_m;    // != 0: the order statistic of the LAST level, whatever F is (retry batches: k, the proven threshold)
+};
+
+// level of a block: the first level whose stride divides it
+__host__ __device__ static inline uint32_t hvs_block_level(const HvsLevels& L, uint32_t b)
+{
+    uint32_t j = 0;
+    while (j < L.K && (b & (L.stride[j] - 1u)) != 0u) ++j;  // (strides are powers of two)
+    return j;
+}
+
+// rows of position range [a, b) that lie in levels < `level` (exact: whole blocks of the level runs, less the parts of the
+// range's first and last block that are outside it)
+__host__ __device__ static inline uint32_t hvs_rows_seen_before(const HvsLevels& L, uint32_t level, uint32_t a, uint32_t b)
+{
+    if (b <= a) return 0u;
+    const uint32_t fb = a / 32u, lb = (b - 1u) / 32u;
+    uint32_t rows = 0;
+    for (uint32_t j = 0; j < level; ++j) {
+        uint32_t lo, hi;
+        hvs_level_run(L, j, fb, lb + 1u, lo, hi);
+        rows += (hi - lo) * 32u;
+    }
+    if (hvs_block_level(L, fb) < level) rows -= a - fb * 32u;
+    if (hvs_block_level(L, lb) < level) rows -= (lb + 1u) * 32u - b;
+    return rows;
+}
+
+// order statistic for the threshold of `level` for a query with position range [a, b)
+__device__ __forceinline__ uint32_t hvs_guess_m(const HvsLevels& L, const HvsGuessTable& G, uint32_t level, uint32_t a, uint32_t b,
+                                                uint32_t knn)
+{
+    if (level == L.K && G.last_m) return G.last_m < knn ? G.last_m : knn;
+    const uint32_t seen = hvs_rows_seen_before(L, level, a, b);
+    if (seen == 0u || b <= a) return knn;
+    const float lf = __log2f((float)(b - a) / (float)seen);  // -log2 F >= 0
+    int idx = (int)ceilf(8.0f * lf - 0.02f);
+    idx = idx < 0 ? 0 : (idx >= HVS_GUESS_STEPS ? HVS_GUESS_STEPS - 1 : idx);
+    uint32_t m = G.m[idx];
+    m = m < G.floor_m ? G.floor_m : m;
+    return m < knn ? m : knn;
+}
+
 // ---------------------------------------------------------------------------------------------
 // hvs_k_merge -- per slot (one wave): top-k := k smallest keys of (top U cand); the threshold tau of the NEXT level
 // and the filter threshold theta that belongs to it.  With `final` it verifies the answer, pads from the end of D
@@ -2298,10 +2347,12 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
 // so the k-th smallest distance AFTER the level is close to the (k / r)-th smallest BEFORE it.  The merge in front of a
 // level therefore sets
 //     tau_next = min(tau_now, m-th smallest distance held)            (m = m_next <= k; unchanged while fewer are held)
-// with m chosen on the host (hvs.hip, plan_guess): for the levels before the last any small m will do (m = 12: the
-// level then hands ~ m r = 190 rows to the exact kernel whatever k is), for the last level the smallest m whose
-// chance of leaving fewer than k rows below tau is under the target (k = 100, r = 4: m = 46 for 10^-5 -- ~140 rows
-// instead of 300).  Nothing is taken on trust:
+// with m the smallest order statistic whose chance of leaving fewer than k rows of the WHOLE range below tau is under a
+// target (hvs.hip, plan_guess): if a fraction F of the query's rows has been seen, the number of rows of the whole
+// range below the m-th smallest seen distance is m + NegBin(m, F).  k = 100, target 10^-5: F = 1/4 (in front of the
+// last level of radix 4) -> m = 46, the level hands ~140 rows to the exact kernel instead of 300; F = 1/64 -> m = 11;
+// F = 1/1024 -> m = 5.  F is the query's own (hvs_guess_m: a narrow predicate range sees a different share of its rows
+// than the level radices say).  Nothing is taken on trust:
 //   * tau only ever decreases, every row with exact distance <= tau of its level reaches the exact kernel (the filter's
 //     bound, see theta below) and the top-k truncation only drops keys above k kept ones -- so after the last level
 //     the list holds EVERY row of the query's range with distance <= tau_last;
@@ -2325,7 +2376,8 @@ template <bool FINAL, int CAP>
 __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, uint32_t n, const float* __restrict__ Q,
                                                    HvsBatch B, const HvsBounds* __restrict__ bounds, int pad,
                                                    uint32_t* __restrict__ out_ids, float* __restrict__ out_dists, int fmt,
-                                                   const HvsQuant* __restrict__ qz, uint32_t m_next)
+                                                   const HvsQuant* __restrict__ qz, HvsLevels L, uint32_t level_next,
+                                                   HvsGuessTable G)
 {
     __shared__ uint64_t sbuf[4][CAP];
     __shared__ uint32_t shist[4][256];  // digit histograms of the radix select
@@ -2375,7 +2427,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         for (uint32_t e = lane; e < cnt; e += 64u) B.top[(size_t)slot * B.topcap + e] = buf[e];
         // the m_next-th smallest distance held (the largest one when exactly m_next are held)
         uint32_t mth_bits = dmax_bits;
-        const uint32_t mn = m_next < knn ? m_next : knn;
+        const uint32_t mn = __builtin_amdgcn_readfirstlane(hvs_guess_m(L, G, level_next, B.ra[slot], B.rb[slot], knn));
         if (cnt > mn) mth_bits = (uint32_t)(hvs_wave_select_prune<CAP / 64, false>(buf, cnt, mn, lane, shist[w]) >> 32);
         if (lane == 0u) {
             B.topcnt[slot] = cnt;

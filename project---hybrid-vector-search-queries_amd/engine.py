@@ -150,6 +150,7 @@ def library():
         "hvs_export_results_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
         "hvs_merge_shards_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, vp, vp]),
         "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
+        "hvs_last_reruns": (C.c_int, [vp, C.c_int, _u32p, C.c_uint32]),
         "hvs_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
@@ -310,6 +311,16 @@ class Engine:
                                                    C.c_void_p(dists_all_ptr), rows, n_total, C.c_void_p(pad_dists_ptr),
                                                    C.c_void_p(out_ids_ptr),
                                                    C.c_void_p(out_dists_ptr) if out_dists_ptr else None))
+
+    def last_reruns(self, which):
+        """Query indices of the last call answered a second time: which = 0 the exact engine's list, 1 the retry list."""
+        n = self._lib.hvs_last_reruns(self._h, int(which), None, 0)
+        if n < 0:
+            self._ck(n)
+        out = np.empty(n, np.uint32)
+        if n:
+            self._ck(min(0, self._lib.hvs_last_reruns(self._h, int(which), _up(out), n)))
+        return out
 
     def last_timing(self):
         t = Timing()

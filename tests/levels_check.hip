@@ -42,6 +42,32 @@ int main()
             }
             if (covered != (uint64_t)(bhi - blo)) { std::printf("FAIL n=%u: [%u,%u) covered %llu\n", n, blo, bhi, (unsigned long long)covered); return 1; }
         }
+        // rows of a position range that lie in the levels before `level` (the seen fraction behind a guessed threshold)
+        for (int trial = 0; trial < 300; ++trial) {
+            uint32_t a = (uint32_t)rand() % n, len = trial % 3 == 0 ? (uint32_t)rand() % 200u : (uint32_t)rand() % n;
+            uint32_t b = a + len > n ? n : a + len;
+            if (trial == 0) { a = 0; b = n; }
+            for (uint32_t level = 0; level <= L.K + 1u; ++level) {
+                uint64_t want = 0;
+                if (b > a && (b - a) < 200000u) {
+                    for (uint32_t pos = a; pos < b; ++pos) want += hvs_block_level(L, pos / 32u) < level ? 1u : 0u;
+                } else if (b > a) {
+                    for (uint32_t blk = a / 32u; blk <= (b - 1u) / 32u; ++blk) {
+                        if (hvs_block_level(L, blk) >= level) continue;
+                        const uint32_t lo = blk * 32u > a ? blk * 32u : a, hi = (blk + 1u) * 32u < b ? (blk + 1u) * 32u : b;
+                        want += hi - lo;
+                    }
+                }
+                const uint32_t got = hvs_rows_seen_before(L, level, a, b);
+                if (got != want) { std::printf("FAIL n=%u [%u,%u) level %u: seen %u want %llu\n", n, a, b, level, got, (unsigned long long)want); return 1; }
+                if (level == L.K + 1u && got != b - a) { std::printf("FAIL n=%u: all levels do not cover the range\n", n); return 1; }
+            }
+        }
+        for (uint32_t idx = 0; idx < L.nblk; idx += 1u + L.nblk / 5000u) {
+            uint32_t j = 0;
+            while (j < L.K && idx >= L.off[j + 1]) ++j;
+            if (hvs_block_level(L, hvs_storage_to_block(L, idx)) != j) { std::printf("FAIL n=%u: storage %u is level %u\n", n, idx, j); return 1; }
+        }
         for (uint32_t nquads : {1u, 20u, 512u, 2052u}) {
             const HvsSegs S = hvs_make_segs(L, nquads, 512u);
             uint32_t expect_first = 0;
