@@ -48,6 +48,8 @@ def main():
                          "of 256 queries and stops at the first chunk boundary past the cap")
     ap.add_argument("--cpu-queries", type=int, default=2048, help="CPU baseline sample: first N queries of the first timed batch (SURVEY 8d)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory (PCIe-inclusive) leg")
+    ap.add_argument("--no-fixed-q", action="store_true",
+                    help="skip the fixed-Q leg (rank 0's share of the 4x10^6-query set at 1, 2, 4, 8 GPUs, run on this GPU)")
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the result gather even with one rank (rehearsal)")
@@ -238,8 +240,41 @@ def main():
             out["end_to_end"]["ids_identical_to_resident_path"] = bool(e2e_check)
             assert e2e_check, "hvs_query (host path) and the resident path disagree"
 
+    # ---- fixed-Q leg (rank 0, N=1 only): BASELINE's metric is ONE query set of 4x10^6 (src/test.cpp:82-92 times one fixed
+    # set), which an N-GPU run cuts into shares of 4x10^6 / N.  Each share is run on this GPU the way a rank would run it:
+    # resident (one hvs_query_resident call) and from host memory (one hvs_query call, pageable buffers).
+    if rank == 0 and world == 1 and not a.no_fixed_q and a.n == 10_000_000:
+        peak_fq = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
+        fixed = {"query_set": 4_000_000, "note": "one GPU running the share a rank of an N-GPU run gets (D replicated); "
+                 "whole-node rate of such a run = N x the share's rate if every rank does the same", "shares": []}
+        for n_ranks in (1, 2, 4, 8):
+            share = 4_000_000 // n_ranks
+            eng.gen_queries(share, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, first_row=0)
+            eng.query_resident(0, min(share, 65536), 1.0)
+            eng.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.query_resident(0, share, 1.0)
+            eng.sync()
+            res_s = time.perf_counter() - t1
+            tm = eng.last_timing()
+            frac = (200.0 * tm.pairs / (tm.main_kernel_ms / 1e3) / 1e12 / peak_fq) if tm.main_kernel_ms > 0 else None
+            ids_res = eng.download_results(0, share, want_dists=False)
+            q_host = eng.download_queries(0, share)
+            ids_host = np.empty((share, K), np.uint32)
+            t1 = time.perf_counter()
+            eng.query(q_host, 1.0, want_dists=False, out_ids=ids_host)
+            host_s = time.perf_counter() - t1
+            assert np.array_equal(ids_host, ids_res), "fixed-Q leg: host path and resident path disagree"
+            fixed["shares"].append({"n_gpus": n_ranks, "queries": share,
+                                    "resident": {"value": share / res_s, "unit": "queries/s", "ms": res_s * 1e3, "roofline_frac": frac,
+                                                 "filter_launches": tm.main_kernel_launches, "retry_queries": tm.retry_queries},
+                                    "host_to_host": {"value": share / host_s, "unit": "queries/s", "ms": host_s * 1e3}})
+            del q_host, ids_host, ids_res
+        out["fixed_q"] = fixed
+
     # ---- CPU baseline + recall leg (rank 0, N=1 only; the oracle is the checker, never the product)
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+    if rank == 0 and world == 1 and a.cpu_seconds > 0 and min(a.cpu_queries, a.batch) > 0:
         nodes = eng.download_data(0, a.n)
         hw = os.cpu_count() or 1
         m_fixed = min(a.cpu_queries, a.batch)

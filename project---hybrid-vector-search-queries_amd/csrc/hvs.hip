@@ -80,6 +80,7 @@ struct hvs_ctx {
     // ... and per-batch state
     HvsBatch fb{};
     uint32_t fb_slots_cap = 0;
+    size_t fb_cand_entries = 0, fb_pair_entries = 0;  // capacity of fb.cand / fb.pairs in entries
     uint32_t* d_layout = nullptr;
     // work-item lists of the current batch (HvsItems): per-quad block ranges, per-segment counts / offsets, the list
     uint32_t *d_qlo = nullptr, *d_qhi = nullptr, *d_segcnt = nullptr, *d_segoff = nullptr, *d_lvloff = nullptr, *d_cursor = nullptr;
@@ -161,7 +162,7 @@ const uint32_t kRadixMid = kGuess ? pow2_floor(env_u32("HVS_RADIX_MID", HVS_RADI
 // smallest order statistic a guessed threshold may use, and -log10 of the chance that one guess leaves fewer than k rows
 // below it (plan_guess)
 const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 3u, 1u, 256u);
-const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 5u, 1u, 12u);
+const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 3u, 1u, 12u);
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
 
@@ -214,7 +215,10 @@ int kernel_timer_begin(hvs_ctx* c)
 void kernel_timer_end(hvs_ctx* c, int ev)
 {
     if (ev < 0) return;
-    if (hipEventRecord(c->ev_k[2 * ev + 1], c->stream) == hipSuccess) c->n_launch_events = ev + 1;
+    if (hipEventRecord(c->ev_k[2 * ev + 1], c->stream) == hipSuccess)
+        c->n_launch_events = ev + 1;
+    else
+        c->untimed_launches++;  // (main_kernel_ms is then a lower bound: bench.py refuses to price a roofline from it)
 }
 
 // the select / merge / scan kernels exist for two list capacities; `f` gets the capacity as a compile-time constant
@@ -271,7 +275,9 @@ Plan make_plan(uint32_t nqb, uint32_t sn)
     // enough (query-wave x row-chunk) work items to fill 256 CUs x 16 waves, but chunks of >= 2048 rows
     uint32_t want = (8192u + p.qwaves - 1u) / p.qwaves;
     uint32_t max_chunks = std::max(1u, sn / 2048u);
-    p.nchunks = std::max(1u, std::min(std::min(want, max_chunks), 64u));
+    // (a handful of queries -- the filter engines' fallback list -- is one wave per chunk: up to 512 chunks then, so that
+    // a single query does not walk 10^7 rows with 64 waves)
+    p.nchunks = std::max(1u, std::min(std::min(want, max_chunks), p.qwaves <= 2u ? 512u : 64u));
     p.rows_per_chunk = (sn + p.nchunks - 1u) / p.nchunks;
     if (p.rows_per_chunk == 0) p.rows_per_chunk = 1;
     return p;
@@ -584,13 +590,15 @@ int build_index(hvs_ctx* c)
 // ---------------------------------------------------------------------------------------------
 // MFMA engine: one batch
 // ---------------------------------------------------------------------------------------------
-int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
+// `want_fcap`: candidate keys per slot and round the batch needs (HVS_FCAP for ordinary batches; retry batches, which run
+// every level with the proven threshold, ask for more); the lists take whatever the workspace offers beyond that
+int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb, uint32_t want_fcap = HVS_FCAP)
 {
     const uint32_t slots = hvs_ceil_div(nqb + 5u * 32u + (HVS_WG_WAVES + 1u) * HVS_GROUP, HVS_GROUP) * HVS_GROUP;
+    const uint32_t groups = slots / HVS_GROUP;
     HvsBatch& B = c->fb;
+    int rc;
     if (slots > c->fb_slots_cap) {
-        int rc;
-        const uint32_t groups = slots / HVS_GROUP;
 #define HVS_A(field, count) \
     if ((rc = dev_alloc(c, &B.field, (size_t)(count)))) return rc
         HVS_A(qid, slots);
@@ -610,18 +618,28 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
         HVS_A(top, (size_t)slots * 256u);  // stride 128 (k <= 128) or 256
         HVS_A(topcnt, slots);
         HVS_A(tau, slots);
-        HVS_A(cand, (size_t)slots * HVS_FCAP);
         HVS_A(candcnt, slots);
         HVS_A(overflow, slots);
-        HVS_A(pairs, (size_t)groups * HVS_GCAP);
         HVS_A(paircnt, groups);
         HVS_A(goverflow, groups);
 #undef HVS_A
         if (!c->d_layout) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_layout), 16 * sizeof(uint32_t)));
         c->fb_slots_cap = slots;
     }
+    // candidate lists and survivor-entry lists: sized in entries, shared out over the slots / groups of the batch
+    const size_t need_cand = (size_t)slots * want_fcap, need_pairs = (size_t)groups * HVS_GROUP * want_fcap;
+    if (need_cand > c->fb_cand_entries) {
+        if ((rc = dev_alloc(c, &B.cand, need_cand))) return rc;
+        c->fb_cand_entries = need_cand;
+    }
+    if (need_pairs > c->fb_pair_entries) {
+        if ((rc = dev_alloc(c, &B.pairs, need_pairs))) return rc;
+        c->fb_pair_entries = need_pairs;
+    }
     B.nslots = slots;
-    B.ngroups = slots / HVS_GROUP;
+    B.ngroups = groups;
+    B.fcap = (uint32_t)std::min<size_t>(16384u, c->fb_cand_entries / slots);
+    B.gcap = (uint32_t)std::min<size_t>((size_t)HVS_GROUP * 16384u, c->fb_pair_entries / groups);
     B.knn = c->k;
     B.topcap = c->k <= 128u ? 128u : 256u;
     // sort workspace shared with the exact engine
@@ -634,9 +652,9 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb)
 // slot layout, position ranges, norms and B fragments of one batch (shared by the MFMA engine and the
 // range-based exact engine)
 int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt, bool host_counts = false,
-               const uint32_t* list = nullptr)
+               const uint32_t* list = nullptr, uint32_t want_fcap = HVS_FCAP)
 {
-    int rc = ensure_filter_workspace(c, nqb);
+    int rc = ensure_filter_workspace(c, nqb, want_fcap);
     if (rc) return rc;
     HvsBatch& B = c->fb;
     const uint32_t n = c->n;
@@ -787,14 +805,17 @@ uint32_t guess_m(double F, uint32_t k, double target)
     }
     return k;
 }
-// `proven_last` (retry batches): the last level uses m = k and the levels before it a far smaller target
-HvsGuessTable plan_guess(uint32_t k, bool proven_last)
+// `proven` (retry batches; HVS_GUESS=0): m = k at every level -- the proven threshold, which cannot fail (a query that
+// failed under a guess did so because the rows it had seen were unlucky, and a larger guess from the same rows shares
+// that luck)
+HvsGuessTable plan_guess(uint32_t k, bool proven)
 {
     HvsGuessTable G{};
-    const double target = std::pow(10.0, -(double)(proven_last ? 2u * kGuessPfail + 2u : kGuessPfail));
-    for (int i = 0; i < HVS_GUESS_STEPS; ++i) G.m[i] = (uint16_t)(kGuess ? guess_m(std::exp2(-(double)i / 8.0), k, target) : k);
-    G.floor_m = (uint16_t)std::min(k, kGuess ? kGuessMid : k);
-    G.last_m = (uint16_t)((proven_last || !kGuess) ? k : 0u);
+    const double target = std::pow(10.0, -(double)kGuessPfail);
+    for (int i = 0; i < HVS_GUESS_STEPS; ++i)
+        G.m[i] = (uint16_t)((kGuess && !proven) ? guess_m(std::exp2(-(double)i / 8.0), k, target) : k);
+    G.floor_m = (uint16_t)std::min(k, (kGuess && !proven) ? kGuessMid : k);
+    G.last_m = (uint16_t)((proven || !kGuess) ? k : 0u);
     return G;
 }
 
@@ -803,7 +824,14 @@ HvsGuessTable plan_guess(uint32_t k, bool proven_last)
 int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list = nullptr, bool proven_last = false)
 {
     const int fmt = c->tile_fmt;
-    int rc = prep_batch(c, q0, nqb, sn == c->n && !list, fmt, false, list);
+    // a retry batch runs every level with the proven threshold: up to k (radix - 1) candidates per query and level
+    uint32_t want_fcap = HVS_FCAP;
+    if (proven_last) {
+        uint32_t rmax = 2u;
+        for (uint32_t j = 1; j <= c->lv.K; ++j) rmax = std::max(rmax, c->lv.radix[j]);
+        want_fcap = std::max<uint32_t>(HVS_FCAP, hvs_ceil_div(2u * c->k * (rmax - 1u), 256u) * 256u);
+    }
+    int rc = prep_batch(c, q0, nqb, sn == c->n && !list, fmt, false, list, want_fcap);
     if (rc) return rc;
     if ((rc = build_items(c))) return rc;
     HvsBatch& B = c->fb;
@@ -825,7 +853,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     const uint32_t l0blocks = L.off[1] - L.off[0];
     const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
     uint32_t seed_chunks = 1u;
-    if (l0blocks <= HVS_FCAP / 32u && seed_waves < 16384u) seed_chunks = std::min(l0blocks, hvs_ceil_div(16384u, seed_waves));
+    if (l0blocks <= B.fcap / 32u && seed_waves < 16384u) seed_chunks = std::min(l0blocks, hvs_ceil_div(16384u, seed_waves));
     with_cap(c->cap, [&](auto CAPT) {
         hipLaunchKernelGGL((hvs_k_seed_exact<decltype(CAPT)::value>), dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0,
                            c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,
@@ -1134,7 +1162,12 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     if (nq == 0u) return HVS_OK;
     int rc = ensure_queries(c, nq);
     if (rc) return rc;
-    if (c->have_index) return ensure_filter_workspace(c, std::min(nq, kBatchMfma));
+    // (the filter workspace only when a filter engine is going to run: 4096 <= n < 32768 under AUTO has an index for the
+    // range scans of the exact engine, whose batches are kBatch queries)
+    const bool filter_runs = c->have_index && (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
+                                               (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
+    if (filter_runs) return ensure_filter_workspace(c, std::min(nq, kBatchMfma));
+    if (c->have_index) return ensure_filter_workspace(c, std::min(nq, kBatch));
     const uint32_t nqb = std::min(nq, kBatch);
     return ensure_batch_workspace(c, nqb, make_plan(nqb, c->n ? c->n : 1u));
 }
@@ -1176,7 +1209,13 @@ int finish_data(hvs_ctx* c)
     HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
     c->index_ms = ms;
     c->load_ms += ms;
-    if (c->reserve_nq) return leaf_reserve(c, c->reserve_nq);  // the caller announced its call size (hvs_reserve)
+    if (c->reserve_nq) {  // the caller announced its call size (hvs_reserve)
+        // not fatal: D and the index are loaded; the first query allocates what it needs (or reports the failure itself)
+        if (leaf_reserve(c, c->reserve_nq) == HVS_ENOMEM) {
+            (void)hipGetLastError();
+            c->err = "batch workspace not reserved (out of device memory): allocated by the first query";
+        }
+    }
     return HVS_OK;
 }
 

@@ -40,8 +40,8 @@
 #define HVS_QB 4              // query blocks (of 32) per wave in the filter kernel
 #endif
 #define HVS_GROUP (32 * HVS_QB)
-#define HVS_FCAP 1024         // per-query candidate keys per round
-#define HVS_GCAP (HVS_GROUP * 1024) // per-group survivor entries per round
+#define HVS_FCAP 1024         // per-query candidate keys per round (the least: HvsBatch::fcap; small batches get more)
+#define HVS_GCAP (HVS_GROUP * 1024) // per-group survivor entries per round (the least: HvsBatch::gcap)
 #ifndef HVS_SEG
 #define HVS_SEG 256           // row blocks per filter work item (128: -1 % mixed, -2.7 % type-0: twice the item prologues)
 #endif
@@ -607,12 +607,15 @@ struct HvsBatch {
     uint32_t knn;               // k of this batch (hvs_set_k; the reference's KNN_LIMIT, optimized_impl.h:26)
     uint32_t* topcnt;           // [nslots]
     float* tau;                 // [nslots]
-    uint64_t* cand;             // [nslots][HVS_FCAP]
+    uint64_t* cand;             // [nslots][fcap]
+    uint32_t fcap;              // candidate keys per slot and round: HVS_FCAP, more for batches that leave room (retry batches
+                                // run every level with the proven threshold: k (radix - 1) candidates per level)
+    uint32_t gcap;              // survivor entries per group and round (HVS_GCAP or more)
     uint32_t* candcnt;          // [nslots]
     uint32_t* overflow;         // [nslots] 0 = answered; HVS_FAIL_RETRY: run again with proven thresholds; HVS_FAIL_EXACT: exact engine
     uint32_t fail_code;         // what a capacity overflow / failed verification of THIS batch writes there (see hvs_flag_fail)
     // filter output
-    uint64_t* pairs;            // [ngroups][HVS_GCAP]  survivor entries (hvs_entry_make)
+    uint64_t* pairs;            // [ngroups][gcap]  survivor entries (hvs_entry_make)
     uint32_t* paircnt;          // [ngroups]
     uint32_t* goverflow;        // [ngroups]
 };
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
         q2[2 * i] = hvs_f2{v4.x, v4.y};
         q2[2 * i + 1] = hvs_f2{v4.z, v4.w};
     }
-    uint64_t* __restrict__ mylist = B.cand + (size_t)slot * HVS_FCAP;
+    uint64_t* __restrict__ mylist = B.cand + (size_t)slot * B.fcap;
     float tau = __builtin_inff();
     uint32_t cnt = 0, nscan = 0;
     for (uint32_t i = lo + blockIdx.y; i < hi; i += nchunks) {
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
             if (nchunks > 1u) {  // wave-uniform
                 if (pass) {
                     const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
-                    if (k < HVS_FCAP)
+                    if (k < B.fcap)
                         mylist[k] = hvs_make_key(dist, id);
                     else
                         hvs_flag_fail(B.fail_code, B.overflow, slot);
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
                 while (full != 0ull) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(full);
                     full &= full - 1ull;
-                    uint64_t* lst = B.cand + (size_t)(w * 64u + l) * HVS_FCAP;
+                    uint64_t* lst = B.cand + (size_t)(w * 64u + l) * B.fcap;
                     const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, B.knn, lane);
                     if (lane == l) {
                         cnt = B.knn;
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ uint32_t hvs_hit_mask(const ACC& a, THR th)
 // pairs is mostly empty for windowed predicates -- 75 % of the workgroups of a 25 % timestamp window, > 98 % for
 // categorical ones -- and the empties cost ~7 ns each of dispatch time (18 % of a type-2 batch's filter time).
 struct HvsItems {
-    const uint32_t* list;    // items of all levels: (segment within the level << 12) | quad
+    const uint32_t* list;    // items of all levels: (segment within the level << HVS_ITEM_QUAD_BITS) | quad
     const uint32_t* lvloff;  // [K + 2] first item of each level; lvloff[level + 1] - lvloff[level] = the level's items
     uint32_t* cursor;        // [16] next item of each level (zeroed per batch)
     uint32_t segsize;        // row blocks per item at the level being launched (HvsSegs::seg)
@@ -1402,8 +1405,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         if (lane == 0u) base = atomicAdd(&B.paircnt[g], wcnt);
         base = __builtin_amdgcn_readfirstlane(base);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (base + wcnt <= HVS_GCAP) {
-            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * HVS_GCAP + base + e] = lbuf[e];
+        if (base + wcnt <= B.gcap) {
+            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * B.gcap + base + e] = lbuf[e];
         } else if (lane == 0u) {
             B.goverflow[g] = 1u;
         }
@@ -1667,7 +1670,7 @@ __device__ __forceinline__ uint32_t hvs_hit_mask8(const hvs_i32x4& a0, const hvs
 //   hvs_k_quad_ranges : per quad [block lo, block hi) over its groups (those that share the first group's ordering)
 //   hvs_k_item_count  : one workgroup per (level, segment): how many quads cover it
 //   hvs_k_item_scan   : exclusive prefix over all segments (one workgroup) + per-level offsets
-//   hvs_k_item_fill   : the same sweep as the count, writing (segment << 12 | quad) in quad order
+//   hvs_k_item_fill   : the same sweep as the count, writing (segment << HVS_ITEM_QUAD_BITS | quad) in quad order
 // ---------------------------------------------------------------------------------------------
 struct HvsSegs {
     uint32_t first[17];  // first global segment number of each level; first[K + 1] = total
@@ -1878,8 +1881,8 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         if (lane == 0u) base = atomicAdd(&B.paircnt[g], wcnt);
         base = __builtin_amdgcn_readfirstlane(base);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (base + wcnt <= HVS_GCAP) {
-            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * HVS_GCAP + base + e] = lbuf[e];
+        if (base + wcnt <= B.gcap) {
+            for (uint32_t e = lane; e < wcnt; e += 64u) B.pairs[(size_t)g * B.gcap + base + e] = lbuf[e];
         } else if (lane == 0u) {
             B.goverflow[g] = 1u;
         }
@@ -2127,7 +2130,7 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     uint32_t np = B.paircnt[g];
     // a group whose entry list overflowed holds unwritten entries past the failed flush: none of
     // them are used, all of its queries are re-run by the exact engine
-    if (np > HVS_GCAP || B.goverflow[g]) np = 0;
+    if (np > B.gcap || B.goverflow[g]) np = 0;
     if (blockIdx.x == 0u && threadIdx.x == 0u && B.goverflow[g]) {
         for (uint32_t s = 0; s < HVS_GROUP; ++s) hvs_flag_fail(B.fail_code, B.overflow, g * HVS_GROUP + s);
     }
@@ -2170,8 +2173,8 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     #pragma unroll
         for (int u = 0; u < kUn; ++u) {
             if (pend[u]) {
-                if (pend_k[u] < HVS_FCAP)
-                    B.cand[(size_t)pend_slot[u] * HVS_FCAP + pend_k[u]] = pend_key[u];
+                if (pend_k[u] < B.fcap)
+                    B.cand[(size_t)pend_slot[u] * B.fcap + pend_k[u]] = pend_key[u];
                 else
                     hvs_flag_fail(B.fail_code, B.overflow, pend_slot[u]);
             }
@@ -2244,7 +2247,7 @@ __global__ __launch_bounds__(64 * HVS_RESCORE_WAVES) void hvs_k_rescore(const fl
     const uint32_t first = (blockIdx.x * HVS_RESCORE_WAVES + w) * 64u;
     auto load_entry = [&](uint32_t base) -> uint64_t {
         const uint32_t ei = base + lane;
-        return (base < np && ei < np) ? B.pairs[(size_t)g * HVS_GCAP + ei] : 0ull;  // (mask 0: nothing)
+        return (base < np && ei < np) ? B.pairs[(size_t)g * B.gcap + ei] : 0ull;  // (mask 0: nothing)
     };
     struct Staged {
         uint64_t ent;
@@ -2390,11 +2393,11 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     if (qi == 0xFFFFFFFFu) return;
     uint64_t* buf = sbuf[w];
     uint32_t m = B.candcnt[slot];
-    if (m > HVS_FCAP) m = HVS_FCAP;
+    if (m > B.fcap) m = B.fcap;
     if (m == 0u && !FINAL) return;  // nothing new at this level: top-k, tau and theta stand
     uint32_t cnt = B.topcnt[slot];
     for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * B.topcap + e];
-    const uint64_t* __restrict__ lst = B.cand + (size_t)slot * HVS_FCAP;
+    const uint64_t* __restrict__ lst = B.cand + (size_t)slot * B.fcap;
     for (uint32_t off = 0; off < m; off += 64u) {
         if (cnt + 64u > (uint32_t)CAP) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

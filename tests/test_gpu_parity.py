@@ -674,6 +674,68 @@ def test_host_path_stages_every_batch_it_runs(nq, devices):
     T.check_parity(nodes, queries[sel], want[sel], ref)
 
 
+_GUESS_CODE = r"""
+import importlib, os, sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import hvs_testlib as T
+PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
+n, nq = 400_000, 6000
+rng = np.random.default_rng(7)
+def run(nodes, queries, tag, want_retry):
+    with PKG.Engine(0) as x:
+        x.set_engine(PKG.ENGINE_EXACT_SCAN); x.load_data(nodes)
+        want_i, want_d = x.query(queries, 1.0)
+    for engine in (PKG.ENGINE_MFMA_I8, PKG.ENGINE_MFMA_FILTER):
+        with PKG.Engine(0) as e:
+            e.set_engine(engine); e.load_data(nodes)
+            ids, d = e.query(queries, 1.0)
+            t = e.last_timing()
+            assert t.engine == engine
+            bad = np.nonzero((ids != want_i).any(axis=1) | (d.view(np.uint32) != want_d.view(np.uint32)).any(axis=1))[0]
+            assert bad.size == 0, (tag, engine, bad[:8], t.as_dict())
+            print(tag, 'engine', engine, 'retried', t.retry_queries, 'exact fallback', t.fallback_queries, 'rescored/query %.0f' % (t.rescored_pairs / nq))
+            if want_retry: assert t.retry_queries > 0, tag
+            assert len(e.last_reruns(1)) == t.retry_queries and len(e.last_reruns(0)) == t.fallback_queries
+    return want_i
+# 1. uniform data
+nodes = T.gen_data(n, 71, T.GEN_V1, 10); queries = T.gen_queries(nq, 72, T.GEN_V1, 10)
+w = run(nodes, queries, 'uniform', os.environ.get('HVS_GUESS_PFAIL') == '1')
+ref, _ = T.oracle_query(nodes, queries[:96]); T.check_parity(nodes, queries[:96], w[:96], ref)
+# 2. vectors drift with the timestamp: rows that are neighbours in the T ordering are neighbours in space
+drift = nodes.copy(); drift[:, 2:] += 40.0 * drift[:, 1:2] * np.sign(rng.standard_normal(100)).astype(np.float32)
+qd = queries.copy(); qd[:, 4:] += 40.0 * rng.random((nq, 1), dtype=np.float32) * np.sign(rng.standard_normal(100)).astype(np.float32)
+run(drift, qd, 'drift', False)
+# 3. bursts: the true neighbours of a query sit in a few ADJACENT blocks of both orderings (same C, consecutive T), which the
+#    rows seen before a level either miss altogether or over-represent
+burst = nodes.copy(); qb = queries[:2000].copy()
+for j in range(0, 2000, 4):
+    rows = rng.integers(0, n - 200)
+    c, t0 = float(j % 10), 0.2 + 0.6 * rng.random()
+    m = 150
+    burst[rows:rows + m, 0] = c
+    burst[rows:rows + m, 1] = (t0 + 1e-6 * np.arange(m)).astype(np.float32)
+    burst[rows:rows + m, 2:] = qb[j, 4:] + 0.05 * rng.standard_normal((m, 100)).astype(np.float32)
+    typ = j // 4 % 4
+    qb[j, 0] = typ; qb[j, 1] = c if typ in (1, 3) else -1; qb[j, 2:4] = (0.1, 0.9) if typ >= 2 else (-1, -1)
+run(burst, qb, 'burst', False)
+print('SUBPROCESS-OK')
+"""
+
+
+@pytest.mark.parametrize("pfail", ["1", "3", "6"])
+def test_guessed_thresholds_are_verified_whatever_the_guess(pfail):
+    """The filter engines guess each level's threshold from the rows seen so far and verify the answer at the end (csrc/
+    hvs_filter.h, "Guessed thresholds"): with a reckless guess (failure target 10^-1: many queries are retried with the proven
+    threshold), the default and a timid one; on uniform data, on data whose vectors drift along the T ordering and on data
+    whose true neighbours sit in a few adjacent index blocks.  Always bit-equal to the exact engine."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HVS_GUESS_PFAIL=pfail)
+    r = subprocess.run([sys.executable, "-c", _GUESS_CODE], capture_output=True, text=True, env=env, cwd=T.REPO)
+    print(r.stdout[-1500:])
+    assert "SUBPROCESS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_config3_host_path_4e6_queries_one_call():
     """BASELINE configs[3], one GPU's view of it: D = 10^7, the whole 4 x 10^6-query set handed to hvs_query as ONE
     call from host memory (reference scope src/test.cpp:82-88: host RAM in, host RAM out), ids identical to the
