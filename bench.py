@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000, help="rows of D")
     ap.add_argument("--batch", type=int, default=2097152, help="queries per step per GPU")
     ap.add_argument("--force-type", type=int, default=-1, help="-1 mixed types, 0..3 a single type")
+    ap.add_argument("--profile", type=int, default=1,
+                    help="vector law of D and Q (include/hvs_gen.h): 1 gen-v1 uniform (the headline), 2 clustered, 3 PCA-like "
+                         "decaying variances, 4 heavy-tailed norms; 2-4: 1 %% of the queries lie outside the data's box")
     ap.add_argument("--cpu-seconds", type=float, default=60.0,
                     help="time cap of the CPU baseline leg (0 = skip): it times the fixed --cpu-queries prefix in chunks "
                          "of 256 queries and stops at the first chunk boundary past the cap")
@@ -87,13 +90,13 @@ def main():
         eng.set_engine(a.engine)
     eng.reserve(a.batch * total_batches)                                # buffers + batch workspace before anything is timed
     t0 = time.time()
-    eng.gen_data(a.n, T.SEED_DATA, T.GEN_V1, 100)                      # D replicated per GPU
+    eng.gen_data(a.n, T.SEED_DATA, a.profile, 100)                      # D replicated per GPU
     load_s = time.time() - t0
     # Q is partitioned: this rank owns one contiguous range of the query stream (sharding.shard_range)
     sharding = importlib.import_module("project---hybrid-vector-search-queries_amd.sharding")
     q_first, q_last = sharding.shard_range(world * a.batch * total_batches, rank, world)
     assert q_last - q_first == a.batch * total_batches
-    eng.gen_queries(a.batch * total_batches, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, first_row=q_first)
+    eng.gen_queries(a.batch * total_batches, T.SEED_QUERY, a.profile, 100, a.force_type, first_row=q_first)
 
     # result gather (N > 1): every rank's block of ids goes to rank 0 over xGMI (RCCL gather; rank 0 alone needs the
     # output.bin rows).  Two send buffers alternate, so a step never waits for the previous step's gather.
@@ -180,7 +183,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"D={a.n} rows x dim 100 replicated per GPU; step = {a.batch} "
                                    f"{'mixed-type' if a.force_type < 0 else 'type-%d' % a.force_type} queries per GPU "
-                                   f"from the gen-v1 4x10^6-query stream, k=100, sample_proportion=1",
+                                   f"from the {['gen-v0', 'gen-v1', 'clustered', 'PCA-like', 'heavy-tailed'][a.profile]} 4x10^6-query stream, "
+                                   f"k=100, sample_proportion=1",
+                       "profile": a.profile,
                        "n": a.n, "queries_per_step_per_gpu": a.batch, "engine": engine_id,
                        "sharding": "Q partitioned across ranks, D replicated, RCCL gather of the ids to rank 0"},
             "roofline": {"bound": "mfma" if engine_id in (2, 3) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -243,7 +248,7 @@ def main():
     # ---- fixed-Q leg (rank 0, N=1 only): BASELINE's metric is ONE query set of 4x10^6 (src/test.cpp:82-92 times one fixed
     # set), which an N-GPU run cuts into shares of 4x10^6 / N.  Each share is run on this GPU the way a rank would run it:
     # resident (one hvs_query_resident call) and from host memory (one hvs_query call, pageable buffers).
-    if rank == 0 and world == 1 and not a.no_fixed_q and a.n == 10_000_000:
+    if rank == 0 and world == 1 and not a.no_fixed_q and a.n == 10_000_000 and a.profile == 1:
         peak_fq = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
         fixed = {"query_set": 4_000_000, "note": "one GPU running the share a rank of an N-GPU run gets (D replicated); "
                  "whole-node rate of such a run = N x the share's rate if every rank does the same", "shares": []}

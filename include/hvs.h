@@ -43,7 +43,9 @@ typedef struct hvs_ctx hvs_ctx;
 #define HVS_ENGINE_EXACT_SCAN 1 /* FP32 exact-order scan of every candidate row (VALU)       */
 #define HVS_ENGINE_MFMA_FILTER 2 /* BF16 MFMA bound filter + exact-order re-scoring (same answers) */
 #define HVS_ENGINE_MFMA_I8 3     /* INT8 MFMA bound filter + exact-order re-scoring (same answers); falls back to
-                                    the BF16 filter for data the INT8 format cannot bound */
+                                    a 16-bit float filter for data the INT8 format cannot bound */
+#define HVS_ENGINE_MFMA_F16 4    /* FP16 MFMA bound filter + exact-order re-scoring (same answers): the BF16 filter's cost,
+                                    an 8x tighter bound; what HVS_ENGINE_AUTO picks for clustered / low-dimensional data */
 
 typedef struct hvs_timing {
     double query_ms;      /* whole vec_query-equivalent region on the device stream (HIP events)   */

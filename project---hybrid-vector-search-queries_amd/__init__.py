@@ -10,9 +10,9 @@ The directory name contains dashes, so import it with
     importlib.import_module("project---hybrid-vector-search-queries_amd")
 """
 from .engine import (Engine, HvsError, Timing, library, library_path, build_library, build_cli, build_seam, seam_path, cli_path, compare_path, exported_symbols,  # noqa: F401
-                     ENGINE_AUTO, ENGINE_EXACT_SCAN, ENGINE_MFMA_FILTER, ENGINE_MFMA_I8)
+                     ENGINE_AUTO, ENGINE_EXACT_SCAN, ENGINE_MFMA_FILTER, ENGINE_MFMA_I8, ENGINE_MFMA_F16)
 from .vec_query import vec_query, ReadBin, SaveKNN, SaveKNNFull, calc_dist  # noqa: F401
 
 __all__ = ["Engine", "HvsError", "Timing", "library", "library_path", "build_library", "build_cli", "build_seam", "seam_path", "cli_path", "compare_path", "exported_symbols",
            "vec_query", "ReadBin", "SaveKNN", "SaveKNNFull", "calc_dist",
-           "ENGINE_AUTO", "ENGINE_EXACT_SCAN", "ENGINE_MFMA_FILTER", "ENGINE_MFMA_I8"]
+           "ENGINE_AUTO", "ENGINE_EXACT_SCAN", "ENGINE_MFMA_FILTER", "ENGINE_MFMA_I8", "ENGINE_MFMA_F16"]

@@ -75,6 +75,8 @@ struct hvs_ctx {
     int planned_fmt = HVS_FMT_BF16;                       // what HVS_ENGINE_AUTO uses for this data set
     bool i8_usable = false;
     bool i8_rejected = false;  // the INT8 tiles were built and their bound was unusable: do not try again
+    bool f16_rejected = false; // likewise the FP16 tiles (components beyond the half-precision range)
+    float probe_cost[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // planner probe: modelled cost per format (0: not probed), see probe_format
     double index_ms = 0.0;
     bool index_too_large = false;  // more than 2^27 rows: no filter index (hvs_timing.flags says so)
     // ... and per-batch state
@@ -387,18 +389,20 @@ void free_index(hvs_ctx* c)
     c->tile_fmt = HVS_FMT_NONE;
     c->i8_usable = false;
     c->i8_rejected = false;
+    c->f16_rejected = false;
 }
 
-// Planner of HVS_ENGINE_AUTO: which tile format filters this data set more cheaply.  The INT8 filter does
-// 4 matrix instructions per tile instead of 7 at the same instruction rate (measured 1.8-1.9x the tile rate,
-// scripts/mfma_i8_lab.hip) but its error band can be wider, which inflates the number of survivors the exact
-// kernel re-scores by about exp(z * 2 band / sigma): sigma = spread of squared distances between rows,
-// z = how many sigmas below the mean the 100th neighbour of n rows sits.  Everything here is an estimate
-// from a sample of rows -- it decides speed only, both formats give the same answers.
+// Planner of HVS_ENGINE_AUTO, first guess: which tile format filters this data set more cheaply.  The INT8 filter runs
+// at about twice the tile rate of the 16-bit float filters (profiles/) but its error band can be wider, and the FP16
+// band is 8x tighter than the BF16 one at the same cost; a wider band inflates the number of survivors the exact kernel
+// re-scores by about exp(z * 2 band / sigma): sigma = spread of squared distances between rows, z = how many sigmas
+// below the mean the k-th neighbour of n rows sits.  Everything here is an estimate from a sample of rows and a
+// unimodal model of the distances -- build_index checks the choice with a probe batch (probe_format) -- and it decides
+// speed only: all formats give the same answers.
 int choose_format(hvs_ctx* c)
 {
     const uint32_t n = c->n;
-    c->planned_fmt = HVS_FMT_BF16;
+    c->planned_fmt = HVS_FMT_F16;
     c->i8_usable = false;
     if (!c->d_quant) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_quant), sizeof(HvsQuant)));
     hipLaunchKernelGGL(hvs_k_quant_reset, dim3(1), dim3(128), 0, c->stream, c->d_quant);
@@ -418,28 +422,34 @@ int choose_format(hvs_ctx* c)
                               hipMemcpyDeviceToHost, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->i8_usable = sd > 0.0 && std::isfinite(sd);
-    if (!c->i8_usable || hb.pair_n < 16u) return HVS_OK;
-    const double mean = hb.pair_sum / hb.pair_n;
-    const double var = hb.pair_sumsq / hb.pair_n - mean * mean;
-    const double sigma = std::sqrt(std::max(var, 1e-300));
-    // z of the 100th neighbour among n rows (normal tail, crude): 100/n = Phi(-z)
-    const double pq = std::min(0.4, 100.0 / (double)n);
-    const double z = std::sqrt(std::max(0.0, -2.0 * std::log(pq) - std::log(-2.0 * std::log(pq) * 6.2832)));
-    // bands for a query that looks like a row (|q| ~ row norm, quantisation error ~ row error)
-    const double band16 = 2.0 * (double)hb.nb_d * (double)hb.e_d + 4.0e-5 * ((double)hb.nb_d * (double)hb.nb_d + (double)hb.hmax);
-    const double band8 = 2.0 * (double)hb.n_d8 * (double)hb.e_d8;
-    const double infl16 = std::exp(std::min(50.0, z * 2.0 * band16 / sigma));
-    const double infl8 = std::exp(std::min(50.0, z * 2.0 * band8 / sigma));
-    // cost model in units of one INT8 filter launch: the BF16 filter takes kPlanBf16 times as long, re-scoring
-    // kPlanRescore times at inflation 1 and grows with the candidates.  Defaults = this round's measurement on
-    // D = 1e7, 2^20 mixed queries (profiles/r02_i8x16: 44.7 / 23.0 ms per filter launch, 6.9 ms re-scoring per level);
-    // HVS_PLAN_BF16_COST / HVS_PLAN_RESCORE_COST (in hundredths) override them for other chips or data shapes.
-    const double kPlanBf16 = env_u32("HVS_PLAN_BF16_COST", 194u, 100u, 1000u) / 100.0;
-    const double kPlanRescore = env_u32("HVS_PLAN_RESCORE_COST", 30u, 1u, 1000u) / 100.0;
-    const double cost16 = kPlanBf16 + kPlanRescore * infl16, cost8 = 1.0 + kPlanRescore * infl8;
-    c->planned_fmt = (cost8 < cost16 && infl8 < 6.0) ? kI8Fmt : HVS_FMT_BF16;
-    if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "i8"
+    const bool f16_ok = std::isfinite(hb.nb_df) && std::isfinite(hb.e_df) && hb.hmax < 3.0e4f;
+    if (!f16_ok) c->planned_fmt = HVS_FMT_BF16;
+    if (hb.pair_n >= 16u) {
+        const double mean = hb.pair_sum / hb.pair_n;
+        const double var = hb.pair_sumsq / hb.pair_n - mean * mean;
+        const double sigma = std::sqrt(std::max(var, 1e-300));
+        // z of the k-th neighbour among n rows (normal tail, crude): k/n = Phi(-z)
+        const double pq = std::min(0.4, (double)c->k / (double)n);
+        const double z = std::sqrt(std::max(0.0, -2.0 * std::log(pq) - std::log(-2.0 * std::log(pq) * 6.2832)));
+        // bands for a query that looks like a row (|q| ~ row norm, quantisation error ~ row error)
+        const double acc16 = 4.0e-5 * ((double)hb.nb_d * (double)hb.nb_d + (double)hb.hmax);
+        const double band_bf = 2.0 * (double)hb.nb_d * (double)hb.e_d + acc16;
+        const double band_f = 2.0 * (double)hb.nb_df * (double)hb.e_df + acc16;
+        const double band8 = 2.0 * (double)hb.n_d8 * (double)hb.e_d8;
+        const double infl_bf = std::exp(std::min(50.0, z * 2.0 * band_bf / sigma));
+        const double infl_f = std::exp(std::min(50.0, z * 2.0 * band_f / sigma));
+        const double infl8 = std::exp(std::min(50.0, z * 2.0 * band8 / sigma));
+        // cost model in units of one INT8 filter launch: a 16-bit float filter takes kPlan16 times as long, re-scoring
+        // kPlanRescore times at inflation 1 and grows with the candidates (HVS_PLAN_BF16_COST / HVS_PLAN_RESCORE_COST, in
+        // hundredths, override the measured defaults of profiles/)
+        const double kPlan16 = env_u32("HVS_PLAN_BF16_COST", 194u, 100u, 1000u) / 100.0;
+        const double kPlanRescore = env_u32("HVS_PLAN_RESCORE_COST", 15u, 1u, 1000u) / 100.0;
+        const double cost_f = kPlan16 + kPlanRescore * (f16_ok ? infl_f : infl_bf), cost8 = 1.0 + kPlanRescore * infl8;
+        if (c->i8_usable && cost8 < cost_f && infl8 < 6.0) c->planned_fmt = kI8Fmt;
+    }
+    if (const char* f = std::getenv("HVS_FILTER_FORMAT")) {  // A/B override: "bf16" / "f16" / "i8"
         if (!std::strcmp(f, "bf16")) c->planned_fmt = HVS_FMT_BF16;
+        if (!std::strcmp(f, "f16")) c->planned_fmt = HVS_FMT_F16;
         if (!std::strcmp(f, "i8")) c->planned_fmt = kI8Fmt;
     }
     return HVS_OK;
@@ -482,9 +492,9 @@ int build_tiles(hvs_ctx* c, int fmt)
                            c->d_tiles_t, reinterpret_cast<int*>(c->d_nrm_t), c->d_bpos_t, c->d_bounds);
     } else {
         hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_tiles_ct,
-                           c->d_bpos_ct, c->d_bounds);
+                           c->d_bpos_ct, c->d_bounds, fmt);
         hipLaunchKernelGGL(hvs_k_build_tiles, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_tiles_t,
-                           c->d_bpos_t, c->d_bounds);
+                           c->d_bpos_t, c->d_bounds, fmt);
     }
     HVS_HIP(c, hipGetLastError());
     HVS_HIP(c, hipStreamSynchronize(c->stream));
@@ -495,6 +505,10 @@ int build_tiles(hvs_ctx* c, int fmt)
     bool ok;
     if (HVS_IS_I8(fmt))
         ok = std::isfinite(hb.e_d8) && std::isfinite(hb.n_d8) && hb.n_d8 < 1.0e15f;
+    else if (fmt == HVS_FMT_F16)
+        // every component and the three pieces of -|d|^2/2 inside the half-precision range (denormal flushing is part of
+        // the bound: HVS_F16_FLUSH)
+        ok = std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho) && hb.hmax < 6.0e4f;
     else
         // (norms near the f32 denormal range: BF16 operands might be flushed by the matrix pipe, which the
         // error bound does not model)
@@ -503,6 +517,150 @@ int build_tiles(hvs_ctx* c, int fmt)
     if (!ok) return HVS_OK;  // have_index stays false
     c->tile_fmt = fmt;
     c->have_index = true;
+    return HVS_OK;
+}
+
+int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list, bool proven_last);
+HvsGuessTable plan_guess(uint32_t k, bool proven);
+
+// the tile format the context's engine setting asks for (HVS_FMT_NONE: HVS_ENGINE_AUTO found no filter worth running)
+int want_format(const hvs_ctx* c)
+{
+    int want;
+    switch (c->engine) {
+        case HVS_ENGINE_MFMA_FILTER: want = HVS_FMT_BF16; break;
+        case HVS_ENGINE_MFMA_F16: want = HVS_FMT_F16; break;
+        case HVS_ENGINE_MFMA_I8: want = c->i8_usable ? kI8Fmt : HVS_FMT_F16; break;
+        default: want = c->planned_fmt; break;
+    }
+    if (HVS_IS_I8(want) && c->i8_rejected) want = HVS_FMT_F16;
+    if (want == HVS_FMT_F16 && c->f16_rejected) want = HVS_FMT_BF16;
+    return want;
+}
+
+// build `want`, or the next format down the chain INT8 -> FP16 -> BF16 whose bound is usable on this data set
+// (have_index stays false when none is)
+int build_tiles_chain(hvs_ctx* c, int want)
+{
+    for (;;) {
+        int rc = build_tiles(c, want);
+        if (rc) return rc;
+        if (c->have_index) return HVS_OK;
+        if (HVS_IS_I8(want)) {
+            c->i8_rejected = true;
+            want = c->f16_rejected ? HVS_FMT_BF16 : HVS_FMT_F16;
+        } else if (want == HVS_FMT_F16) {
+            c->f16_rejected = true;
+            want = HVS_FMT_BF16;
+        } else {
+            return HVS_OK;
+        }
+    }
+}
+
+// Planner of HVS_ENGINE_AUTO, second step: measure instead of model.  A probe batch of 1024 rows of D used as type-0
+// queries (only D is used, cf. README.md:68) runs through the filter engine in the format just built; what it hands to the
+// exact kernel and what it cannot answer is priced in units of the INT8 filter's own time per query:
+//     cost = F + (2650 / n) re-scored pairs per query + 3 retried fraction + 142 exact-engine fraction
+// (F = 1 for INT8 tiles, 1.94 for 16-bit float tiles; re-scoring 0.07 ns per pair against 0.0266 ns per row and query of the
+// INT8 filter, the exact engine 140x the filter -- profiles/r03), next to its INFLATION = re-scored pairs / what a filter
+// without an error band would hand over under the same guessed thresholds, and the fraction of queries it left unanswered.  The model of choose_format assumes one bell-shaped
+// distance distribution; clustered data and data with a few dominant dimensions have neighbour distances far below what
+// it expects, and an 8-bit grid over the bounding box then lets thousands of rows per query through.
+int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
+{
+    constexpr uint32_t P = 1024;
+    *cost = 1.0e9;
+    // the probe has its own query / result / re-run buffers: resident queries and results of the caller stay untouched
+    float *pq = nullptr, *pdist = nullptr;
+    uint32_t *pids = nullptr, *povf = nullptr, *pretry = nullptr;
+    auto release = [&]() {
+        void* bufs[] = {pq, pdist, pids, povf, pretry};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&pq), (size_t)P * HVS_QCOLS * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&pdist), (size_t)P * c->k * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&pids), (size_t)P * c->k * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&povf), (size_t)P * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&pretry), (size_t)P * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        return fail(c, HVS_ENOMEM, "planner probe: out of device memory");
+    }
+    std::swap(c->d_q, pq);
+    std::swap(c->d_out_ids, pids);
+    std::swap(c->d_out_dists, pdist);
+    std::swap(c->d_ovf_list, povf);
+    std::swap(c->d_retry_list, pretry);
+    const uint32_t step = std::max(1u, c->n / P);
+    hipLaunchKernelGGL(hvs_k_probe_queries, dim3(hvs_ceil_div(P * HVS_QCOLS, 256u)), dim3(256), 0, c->stream, c->d_data, c->n, step, P, c->d_q);
+    hipError_t e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->stream);
+    int rc = e == hipSuccess ? run_batch_mfma(c, 0, P, c->n, nullptr, false) : fail(c, HVS_EHIP, "planner probe: memset failed");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    uint32_t fails[2] = {0, 0};
+    if (!rc) {
+        e = hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fails, c->d_ovf_count, sizeof(fails), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, HVS_EHIP, "planner probe: copy failed");
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(c, HVS_EHIP, "planner probe: synchronisation failed");
+    std::swap(c->d_q, pq);
+    std::swap(c->d_out_ids, pids);
+    std::swap(c->d_out_dists, pdist);
+    std::swap(c->d_ovf_list, povf);
+    std::swap(c->d_retry_list, pretry);
+    release();
+    c->n_launch_events = 0;
+    if (rc) return rc;
+    const double base = HVS_IS_I8(c->tile_fmt) ? 1.0 : env_u32("HVS_PLAN_BF16_COST", 194u, 100u, 1000u) / 100.0;
+    *cost = base + 2650.0 / (double)c->n * ((double)h[2] / P) + 3.0 * fails[1] / P + 142.0 * fails[0] / P;
+    c->probe_cost[c->tile_fmt] = (float)*cost;
+    // what a filter without any error band would have handed over: m (radix - 1) rows per level under the guessed thresholds
+    double ideal = 0.0;
+    {
+        const HvsGuessTable G = plan_guess(c->k, false);
+        double seen = 1.0;  // fraction of the rows seen, from the last level backwards
+        for (uint32_t j = c->lv.K; j >= 1u; --j) {
+            seen /= (double)c->lv.radix[j];
+            int idx = (int)std::ceil(8.0 * -std::log2(seen) - 0.02);
+            idx = std::max(0, std::min(HVS_GUESS_STEPS - 1, idx));
+            const double m = G.last_m && j == c->lv.K ? (double)G.last_m : (double)std::max(G.m[idx], G.floor_m);
+            ideal += std::min(m, (double)c->k) * ((double)c->lv.radix[j] - 1.0);
+        }
+    }
+    *inflation = ideal > 0.0 ? ((double)h[2] / P) / ideal : 1.0;
+    *failed = (double)(fails[0] + fails[1]) / P;
+    return HVS_OK;
+}
+
+// after build_tiles_chain in HVS_ENGINE_AUTO: keep the format the model chose if the probe agrees, else try the next one up
+// the precision chain; planned_fmt = HVS_FMT_NONE when no filter beats the exact engine
+int plan_by_probe(hvs_ctx* c)
+{
+    if (!env_u32("HVS_PLAN_PROBE", 1u, 0u, 1u) || std::getenv("HVS_FILTER_FORMAT")) return HVS_OK;
+    for (float& p : c->probe_cost) p = 0.f;
+    double cost = 0.0, infl = 0.0, failed = 0.0;
+    int rc = probe_format(c, &cost, &infl, &failed);
+    if (rc) return rc;
+    int best = c->tile_fmt;
+    double best_cost = cost;
+    // INT8 tiles stay unless their band visibly lets too much through on this data (the cost formula is not trusted to
+    // split hairs between formats that both work: at small n everything is launch latency)
+    if (HVS_IS_I8(c->tile_fmt) && (infl > 2.5 || failed > 0.01) && !c->f16_rejected) {
+        const int had = c->tile_fmt;
+        if ((rc = build_tiles_chain(c, HVS_FMT_F16))) return rc;
+        if (c->have_index && (rc = probe_format(c, &cost, &infl, &failed))) return rc;
+        if (c->have_index && cost < best_cost) {
+            best = c->tile_fmt;
+            best_cost = cost;
+        } else if ((rc = build_tiles_chain(c, had))) {
+            return rc;
+        }
+    }
+    if (best_cost >= 140.0) best = HVS_FMT_NONE;  // no filter beats the exact engine's range scans here
+    c->planned_fmt = best;
     return HVS_OK;
 }
 
@@ -569,21 +727,19 @@ int build_index(hvs_ctx* c)
         free_index(c);
         return rc;
     }
-    int fmt = c->planned_fmt;
-    if (c->engine == HVS_ENGINE_MFMA_FILTER) fmt = HVS_FMT_BF16;
-    if (c->engine == HVS_ENGINE_MFMA_I8 && c->i8_usable) fmt = kI8Fmt;
-    if ((rc = build_tiles(c, fmt))) {
+    const int fmt = want_format(c);
+    if (fmt != HVS_FMT_NONE && (rc = build_tiles_chain(c, fmt))) {
         free_index(c);
         return rc;
     }
-    if (!c->have_index && HVS_IS_I8(fmt)) {
-        c->i8_rejected = true;
-        if ((rc = build_tiles(c, HVS_FMT_BF16))) {
+    if (fmt != HVS_FMT_NONE && !c->have_index) free_index(c);  // no format has a usable bound: exact engine only
+    if (fmt == HVS_FMT_NONE) c->have_index = true;              // (orderings only: the exact engine's range scans)
+    if (c->have_index && c->tile_fmt != HVS_FMT_NONE && c->engine == HVS_ENGINE_AUTO && n >= kMfmaMinRows) {
+        if ((rc = plan_by_probe(c))) {
             free_index(c);
             return rc;
         }
     }
-    if (!c->have_index) free_index(c);  // neither format has a usable bound: exact engine only
     return HVS_OK;
 }
 
@@ -678,8 +834,10 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt,
                                          (size_t)nqb, 0, 64, c->stream));
     hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, B.qid,
                        B.rank, c->d_layout);
+    // (last argument: the batch is for a filter engine -- `host_counts` is the exact engine's range scan, which answers every
+    // query itself, non-finite ones included)
     hipLaunchKernelGGL(hvs_k_prep_slots, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, B, c->d_keys_ct,
-                       c->d_keys_t, n, count_pairs ? 1 : 0, c->d_counters, fmt, c->d_quant);
+                       c->d_keys_t, n, count_pairs ? 1 : 0, c->d_counters, fmt, c->d_quant, c->d_bounds, host_counts ? 0 : 1);
     hipLaunchKernelGGL(hvs_k_prep_groups, dim3(B.ngroups), dim3(HVS_GROUP), 0, c->stream, c->d_q, B, fmt, c->d_quant);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
@@ -821,7 +979,7 @@ HvsGuessTable plan_guess(uint32_t k, bool proven)
 
 // One batch through the filter engine: the resident range [q0, q0 + nqb), or the nqb query indices in the device array
 // `list` (retry batches: `proven_last`, failures go to the exact engine).
-int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list = nullptr, bool proven_last = false)
+int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list, bool proven_last)
 {
     const int fmt = c->tile_fmt;
     // a retry batch runs every level with the proven threshold: up to k (radix - 1) candidates per query and level
@@ -889,6 +1047,9 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
                                    c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             else if (fmt == HVS_FMT_I8)
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_I8>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
+                                   c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
+            else if (fmt == HVS_FMT_F16)
+                hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_F16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
                                    c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             else
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_BF16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
@@ -996,23 +1157,18 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     // exact stages drop them, so its candidate lists grow by n/sn -- used down to sn = n/4, below that
     // the exact engine answers.
     bool mfma = c->have_index && sn >= c->n / 4u && sn > 0u && !c->scalar_order &&
-                (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
-                 (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
+                (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 || c->engine == HVS_ENGINE_MFMA_F16 ||
+                 (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows && c->planned_fmt != HVS_FMT_NONE));
     if (mfma) {
         // the tiles exist in one format at a time: an engine choice made after the load rebuilds them
-        int want = c->engine == HVS_ENGINE_MFMA_FILTER ? HVS_FMT_BF16
-                   : c->engine == HVS_ENGINE_MFMA_I8   ? (c->i8_usable && !c->i8_rejected ? kI8Fmt : HVS_FMT_BF16)
-                                                       : c->planned_fmt;
-        if (HVS_IS_I8(want) && c->i8_rejected) want = HVS_FMT_BF16;
+        const int want = want_format(c);
         if (want != c->tile_fmt) {
-            const int had = c->tile_fmt;
-            int rc = build_tiles(c, want);
+            int rc = build_tiles_chain(c, want);
             if (rc) return rc;
-            if (!c->have_index) {  // no usable bound in that format: remember it, go back
-                if (HVS_IS_I8(want)) c->i8_rejected = true;
-                if ((rc = build_tiles(c, had))) return rc;
+            if (!c->have_index) {  // no usable bound at all: orderings only, the exact engine answers
+                c->have_index = true;
+                mfma = false;
             }
-            if (!c->have_index) return fail(c, HVS_ESTATE, "internal: tile rebuild lost the index");
         }
     }
     c->timing_valid = false;
@@ -1030,7 +1186,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
         const uint32_t nqb = sched[b];
         int rc = hooks.before(off, nqb);
         if (rc) return rc;
-        rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn)
+        rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn, nullptr, false)
                   : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
         if (rc) return rc;
         if ((rc = hooks.after(off, nqb, b + 1 < sched.size() ? sched[b + 1] : 0u))) return rc;
@@ -1044,7 +1200,8 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     }
     c->timing = hvs_timing{};
     c->timing.nq = nq;
-    c->timing.engine = mfma ? (HVS_IS_I8(c->tile_fmt) ? HVS_ENGINE_MFMA_I8 : HVS_ENGINE_MFMA_FILTER) : HVS_ENGINE_EXACT_SCAN;
+    c->timing.engine = mfma ? (HVS_IS_I8(c->tile_fmt) ? HVS_ENGINE_MFMA_I8 : c->tile_fmt == HVS_FMT_F16 ? HVS_ENGINE_MFMA_F16 : HVS_ENGINE_MFMA_FILTER)
+                          : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
     c->timing.n_gpus = 1;
     c->timing.flags = c->index_too_large ? HVS_TIMING_INDEX_TOO_LARGE : 0u;
@@ -1165,7 +1322,8 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     // (the filter workspace only when a filter engine is going to run: 4096 <= n < 32768 under AUTO has an index for the
     // range scans of the exact engine, whose batches are kBatch queries)
     const bool filter_runs = c->have_index && (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
-                                               (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows));
+                                               c->engine == HVS_ENGINE_MFMA_F16 ||
+                                               (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows && c->planned_fmt != HVS_FMT_NONE));
     if (filter_runs) return ensure_filter_workspace(c, std::min(nq, kBatchMfma));
     if (c->have_index) return ensure_filter_workspace(c, std::min(nq, kBatch));
     const uint32_t nqb = std::min(nq, kBatch);
@@ -1193,7 +1351,9 @@ int finish_data(hvs_ctx* c)
     c->load_ms = ms;
     free_index(c);
     // the index (two orderings + tiles) serves both engines: the exact engine scans position ranges
-    if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER && c->engine != HVS_ENGINE_MFMA_I8) return HVS_OK;
+    if (c->n < kIndexMinRows && c->engine != HVS_ENGINE_MFMA_FILTER && c->engine != HVS_ENGINE_MFMA_I8 &&
+        c->engine != HVS_ENGINE_MFMA_F16)
+        return HVS_OK;
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     int rc = build_index(c);
     if (rc == HVS_ENOMEM) {
@@ -1707,12 +1867,12 @@ int hvs_set_engine(hvs_ctx* c, int engine)
 {
     if (!c) return HVS_EINVAL;
     if (engine != HVS_ENGINE_AUTO && engine != HVS_ENGINE_EXACT_SCAN && engine != HVS_ENGINE_MFMA_FILTER &&
-        engine != HVS_ENGINE_MFMA_I8)
+        engine != HVS_ENGINE_MFMA_I8 && engine != HVS_ENGINE_MFMA_F16)
         return fail(c, HVS_EINVAL, "hvs_set_engine: unknown engine");
     c->engine = engine;
     if (!c->kids.empty()) return for_each_leaf(c, [&](uint32_t r) { return hvs_set_engine(c->kids[r], engine); });
     if (c->d_data && !c->have_index &&
-        (engine == HVS_ENGINE_MFMA_FILTER || engine == HVS_ENGINE_MFMA_I8 || c->n >= kIndexMinRows)) {
+        (engine == HVS_ENGINE_MFMA_FILTER || engine == HVS_ENGINE_MFMA_I8 || engine == HVS_ENGINE_MFMA_F16 || c->n >= kIndexMinRows)) {
         HVS_HIP(c, hipSetDevice(c->device));
         return build_index(c);
     }

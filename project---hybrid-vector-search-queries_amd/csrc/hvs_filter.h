@@ -81,7 +81,11 @@ typedef int hvs_i32x16 __attribute__((ext_vector_type(16)));
 #define HVS_FMT_BF16 1
 #define HVS_FMT_I8 2
 #define HVS_FMT_I8X16 3        // INT8 operands laid out for v_mfma_i32_16x16x64_i8 (same quantisation and bound as HVS_FMT_I8)
+#define HVS_FMT_F16 4          // the BF16 layout and bound with IEEE half operands (v_mfma_f32_32x32x16_f16): 11 instead of 8
+                               // significant bits per element -- an 8x tighter band at the BF16 filter's cost, for data whose
+                               // neighbour distances are small against its extent (clusters, few dominant dimensions)
 #define HVS_IS_I8(fmt) ((fmt) == HVS_FMT_I8 || (fmt) == HVS_FMT_I8X16)
+#define HVS_IS_H16(fmt) ((fmt) == HVS_FMT_BF16 || (fmt) == HVS_FMT_F16)
 #define HVS_I8_KSTEPS 4        // 4 MFMA k-steps of 32 (K padded 100 -> 128)
 #define HVS_I8_KMEM 3          // k-steps stored as full fragments (dims 0..95); the 4th holds 4 real dimensions
 #define HVS_I8_TILE_U4 (HVS_I8_KMEM * 64)  // uint4 per 32-row INT8 tile (3 KiB)
@@ -120,6 +124,21 @@ __device__ __forceinline__ uint16_t hvs_bf16_bits(float f)
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // round to nearest even
 }
 __device__ __forceinline__ float hvs_bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// IEEE half, round to nearest even (values beyond 65504 become inf: such data fails the format's finiteness check)
+__device__ __forceinline__ uint16_t hvs_f16_bits(float f)
+{
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float hvs_f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+// element of a 16-bit float tile format
+__device__ __forceinline__ uint16_t hvs_h16_bits(int fmt, float f) { return fmt == HVS_FMT_F16 ? hvs_f16_bits(f) : hvs_bf16_bits(f); }
+__device__ __forceinline__ float hvs_h16_to_f32(int fmt, uint16_t b) { return fmt == HVS_FMT_F16 ? hvs_f16_to_f32(b) : hvs_bf16_to_f32(b); }
+// The matrix pipe may flush half-precision denormals (|x| < 2^-14) to zero; the bound then sees an operand that differs
+// from the converted value by up to 2^-14 per element: HVS_F16_FLUSH = sqrt(100) 2^-14 is added to every error norm of the
+// F16 format (rows, queries) and 3 x 2^-14 to rho (the three pieces of -|d|^2/2), so the bound holds either way.
+#define HVS_F16_FLUSH 6.103515625e-4
+#define HVS_F16_FLUSH_RHO 1.8310546875e-4
 
 __device__ __forceinline__ float hvs_round_up_f32(double x)
 {
@@ -256,6 +275,8 @@ struct HvsBounds {  // global maxima over rows, all rounded up
     // INT8 format (d' = d - center, dq = int8 image of d'):
     float e_d8;   // max |d' - sd dq|_2
     float n_d8;   // max |d'|_2
+    // planner sample only: the F16 format's counterparts of e_d / nb_d
+    float e_df, nb_df;
     // planner sample: sum and sum of squares of |a-b|^2 over sampled pairs of rows, and their number
     double pair_sum, pair_sumsq;
     uint32_t pair_n;
@@ -483,13 +504,16 @@ __global__ void hvs_k_plan_stats(const float* __restrict__ D, uint32_t n, uint32
     const float* __restrict__ a = D + (size_t)i * HVS_DCOLS + 2;
     const float* __restrict__ bb = D + (size_t)j * HVS_DCOLS + 2;
     const double sd = qz->sd, inv_sd = qz->inv_sd;
-    double nd = 0.0, e2 = 0.0, nb2 = 0.0, nd8 = 0.0, e28 = 0.0, dist = 0.0;
+    double nd = 0.0, e2 = 0.0, nb2 = 0.0, nd8 = 0.0, e28 = 0.0, dist = 0.0, e2f = 0.0, nb2f = 0.0;
     for (int k = 0; k < HVS_NDIM; ++k) {
         const float x = a[k];
         const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+        const float xf = hvs_f16_to_f32(hvs_f16_bits(x));
         nd += (double)x * (double)x;
         e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
         nb2 += (double)xb * (double)xb;
+        e2f += ((double)x - (double)xf) * ((double)x - (double)xf);
+        nb2f += (double)xf * (double)xf;
         const double x8 = (double)x - (double)qz->center[k];
         const double xq = sd * (double)hvs_quant_i8(x8, inv_sd);
         nd8 += x8 * x8;
@@ -503,6 +527,12 @@ __global__ void hvs_k_plan_stats(const float* __restrict__ D, uint32_t n, uint32
     hvs_atomic_max_pos(&bounds->hmax, hvs_round_up_f32(0.5 * nd));
     hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e28)));
     hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd8)));
+    if (nb2f < 1.0e30) {
+        hvs_atomic_max_pos(&bounds->e_df, hvs_round_up_f32(sqrt(e2f) + HVS_F16_FLUSH));
+        hvs_atomic_max_pos(&bounds->nb_df, hvs_round_up_f32(sqrt(nb2f)));
+    } else {
+        bounds->nb_df = __builtin_inff();  // a component beyond the half-precision range: F16 unusable
+    }
     if (i != j && dist < 1.0e30) {
         atomicAdd(&bounds->pair_sum, dist);
         atomicAdd(&bounds->pair_sumsq, dist * dist);
@@ -511,10 +541,11 @@ __global__ void hvs_k_plan_stats(const float* __restrict__ D, uint32_t n, uint32
 }
 
 // one wave per storage block: builds the 7 KiB A-operand tile and the row bounds
+// (`fmt`: HVS_FMT_BF16 or HVS_FMT_F16 -- the element type of the 16-bit float layout)
 __global__ __launch_bounds__(256) void hvs_k_build_tiles(const float* __restrict__ D, uint32_t n,
                                                          const uint32_t* __restrict__ perm, HvsLevels L,
                                                          uint4* __restrict__ tiles, uint32_t* __restrict__ blockpos,
-                                                         HvsBounds* __restrict__ bounds)
+                                                         HvsBounds* __restrict__ bounds, int fmt)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -529,24 +560,26 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles(const float* __restrict
     double nd = 0.0, e2 = 0.0, nb2 = 0.0;
     for (int k = 0; k < HVS_NDIM; ++k) {
         const float x = row[k];
-        const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+        const float xb = hvs_h16_to_f32(fmt, hvs_h16_bits(fmt, x));
         nd += (double)x * (double)x;
         e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
         nb2 += (double)xb * (double)xb;
     }
-    // h = -|d|^2/2 as three BF16 pieces; invalid (padding) rows get a huge negative bias
-    float hf = valid ? (float)(-0.5 * nd) : -1.0e30f;
-    const uint16_t h0 = hvs_bf16_bits(hf);
-    const float r1 = valid ? hf - hvs_bf16_to_f32(h0) : 0.0f;
-    const uint16_t h1 = hvs_bf16_bits(r1);
-    const float r2 = r1 - hvs_bf16_to_f32(h1);
-    const uint16_t h2 = hvs_bf16_bits(r2);
+    // h = -|d|^2/2 as three 16-bit pieces; invalid (padding) rows get a huge negative bias (the largest finite half in
+    // the F16 format, whose thresholds never come near it: test on the row's validity keeps padding rows out anyway)
+    float hf = valid ? (float)(-0.5 * nd) : (fmt == HVS_FMT_F16 ? -65504.0f : -1.0e30f);
+    const uint16_t h0 = hvs_h16_bits(fmt, hf);
+    const float r1 = valid ? hf - hvs_h16_to_f32(fmt, h0) : 0.0f;
+    const uint16_t h1 = hvs_h16_bits(fmt, r1);
+    const float r2 = r1 - hvs_h16_to_f32(fmt, h1);
+    const uint16_t h2 = hvs_h16_bits(fmt, r2);
     if (valid && h == 0u) {
-        const double hs = (double)hvs_bf16_to_f32(h0) + (double)hvs_bf16_to_f32(h1) + (double)hvs_bf16_to_f32(h2);
-        hvs_atomic_max_pos(&bounds->e_d, hvs_round_up_f32(sqrt(e2)));
+        const double hs = (double)hvs_h16_to_f32(fmt, h0) + (double)hvs_h16_to_f32(fmt, h1) + (double)hvs_h16_to_f32(fmt, h2);
+        const double flush = fmt == HVS_FMT_F16 ? HVS_F16_FLUSH : 0.0, flush_rho = fmt == HVS_FMT_F16 ? HVS_F16_FLUSH_RHO : 0.0;
+        hvs_atomic_max_pos(&bounds->e_d, hvs_round_up_f32(sqrt(e2) + flush));
         hvs_atomic_max_pos(&bounds->nb_d, hvs_round_up_f32(sqrt(nb2)));
         hvs_atomic_max_pos(&bounds->hmax, hvs_round_up_f32(0.5 * nd));
-        hvs_atomic_max_pos(&bounds->rho, hvs_round_up_f32(fabs(0.5 * nd + hs) + 1e-30));
+        hvs_atomic_max_pos(&bounds->rho, hvs_round_up_f32(fabs(0.5 * nd + hs) + flush_rho + 1e-30));
     }
 #pragma unroll
     for (int s = 0; s < HVS_KSTEPS; ++s) {
@@ -559,7 +592,7 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles(const float* __restrict
                 const int k = 16 * s + 8 * (int)h + 2 * p + e;
                 uint16_t v;
                 if (k < HVS_NDIM)
-                    v = valid ? hvs_bf16_bits(row[k]) : (uint16_t)0;
+                    v = valid ? hvs_h16_bits(fmt, row[k]) : (uint16_t)0;
                 else if (k == 100)
                     v = h0;
                 else if (k == 101)
@@ -598,7 +631,7 @@ struct HvsBatch {
     float* theta;               // [nslots] BF16 format: discard a row when its MFMA value is < theta
     int* thetai;                // same storage, INT8 format: integer threshold
     double* qn;                 // [nslots] |q|^2
-    float* normq;               // [nslots] |q| (rounded up)
+    float* normq;               // [nslots] BF16 format: |q| (rounded up); INT8 formats: the band's clip term (hvs_k_prep_slots)
     float* eq;                  // [nslots] |q - bf16(q)| (rounded up)
     float* nqb;                 // [nslots] |bf16(q)| (rounded up)
     // top-k state
@@ -804,58 +837,79 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
 }
 
 // per slot: position range of the predicate, norms, bound inputs; resets the top-k state
+//
+// INT8 formats, queries outside the data's bounding box: a coordinate beyond +-127 sd is clipped to +-127, and the part
+// that was cut off, c_k = |q'_k| - 127 sd, multiplies a row coordinate |d'_k| <= H_k (the box's half width in that
+// dimension), so  |(q' - sd qq).d'| <= e_q N_D + sum_k c_k H_k  with e_q now the rounding error of the UNCLIPPED
+// dimensions only.  The sum is kept per slot (`normq`, which the INT8 band does not use otherwise) and hvs_k_merge adds it
+// to the band: a query a little outside the box costs a wider band, not the exact engine.  Far outside (the clip term
+// above 4x the rest of the band) the filter would let most rows through: the exact engine answers.
 __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
                                  const uint64_t* __restrict__ keys_t, uint32_t n, int count_pairs,
-                                 unsigned long long* __restrict__ counters, int fmt, const HvsQuant* __restrict__ qz)
+                                 unsigned long long* __restrict__ counters, int fmt, const HvsQuant* __restrict__ qz,
+                                 const HvsBounds* __restrict__ bounds, int for_filter)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B.nslots) return;
     const uint32_t qi = B.qid[s];
     uint32_t a = 0, b = 0;
-    double qn = 0.0, e2 = 0.0, nb2 = 0.0;
-    bool clipped = false;
+    double qn = 0.0, e2 = 0.0, nb2 = 0.0, clipband = 0.0;
+    bool hopeless = false;
     if (qi != 0xFFFFFFFFu) {
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
         const HvsQParams p = hvs_parse_query(q);
         hvs_query_range(p, keys_ct, keys_t, n, a, b);
         if (HVS_IS_I8(fmt)) {
-            // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2
+            // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2 over the unclipped dimensions
             const double sd = qz->sd, inv_sd = qz->inv_sd;
             for (int k = 0; k < HVS_NDIM; ++k) {
                 const double x = (double)q[4 + k] - (double)qz->center[k];
                 const double xq = sd * (double)hvs_quant_i8(x, inv_sd);
                 qn += x * x;
-                e2 += (x - xq) * (x - xq);
                 nb2 += xq * xq;
-                clipped = clipped || !(fabs(x * inv_sd) <= 127.5);
+                if (fabs(x * inv_sd) <= 127.5) {
+                    e2 += (x - xq) * (x - xq);
+                } else if (x == x) {
+                    const double c = (double)qz->center[k];
+                    const double lo = fabs((double)hvs_attr_key_inv(qz->kmin[k]) - c), hi = fabs((double)hvs_attr_key_inv(qz->kmax[k]) - c);
+                    clipband += fabs(x - xq) * (lo > hi ? lo : hi) * (1.0 + 1e-9);
+                } else {
+                    hopeless = true;  // NaN component
+                }
             }
+            const double rest = sqrt(nb2) * (double)bounds->e_d8 + sqrt(e2) * (double)bounds->n_d8;
+            if (!(clipband <= 4.0 * rest)) hopeless = true;
         } else {
             for (int k = 0; k < HVS_NDIM; ++k) {
                 const float x = q[4 + k];
-                const float xb = hvs_bf16_to_f32(hvs_bf16_bits(x));
+                const float xb = hvs_h16_to_f32(fmt, hvs_h16_bits(fmt, x));
                 qn += (double)x * (double)x;
                 e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
                 nb2 += (double)xb * (double)xb;
             }
+            if (fmt == HVS_FMT_F16) {
+                e2 = (sqrt(e2) + HVS_F16_FLUSH) * (sqrt(e2) + HVS_F16_FLUSH);  // (possible denormal flush, see HVS_F16_FLUSH)
+                if (!(nb2 < 1.0e9)) hopeless = true;                           // a component beyond the half-precision range
+            }
         }
         if (count_pairs) atomicAdd(&counters[0], (unsigned long long)(b - a));
     }
-    // INT8 format: a query outside the data's bounding box is clipped and its band would let nearly every row
-    // through -- flooding the pair list of its whole group.  It is answered by the exact engine instead and takes
-    // no part in the filter (empty range).
-    if (clipped) a = b = 0u;
+    // a query without a usable bound (non-finite components, far outside the data's box) is answered by the exact engine
+    // and takes no part in the filter (empty range)
+    if (!(qn < 1.0e30)) hopeless = true;
+    if (qi == 0xFFFFFFFFu || !for_filter) hopeless = false;  // (the exact engine's range scans use the ranges only)
+    if (hopeless) a = b = 0u;
     B.ra[s] = a;
     B.rb[s] = b;
     B.qn[s] = qn;
-    B.normq[s] = hvs_round_up_f32(sqrt(qn) * (1.0 + 1e-9) + 1e-30);
+    B.normq[s] = HVS_IS_I8(fmt) ? (clipband > 0.0 ? hvs_round_up_f32(clipband) : 0.0f) : hvs_round_up_f32(sqrt(qn) * (1.0 + 1e-9) + 1e-30);
     B.eq[s] = hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30);
     B.nqb[s] = hvs_round_up_f32(sqrt(nb2) * (1.0 + 1e-9) + 1e-30);
     B.topcnt[s] = 0;
     B.candcnt[s] = 0;
-    // a query with non-finite components has no usable bound: it is answered by the exact engine
-    B.overflow[s] = (qi != 0xFFFFFFFFu && (clipped || !(qn < 1.0e30))) ? HVS_FAIL_EXACT : 0u;
+    B.overflow[s] = hopeless ? HVS_FAIL_EXACT : 0u;
     B.tau[s] = __builtin_inff();
-    // -inf: everything in range is a candidate until 100 rows are held; +inf: nothing can ever match
+    // -inf: everything in range is a candidate until a threshold is set; +inf: nothing can ever match
     if (HVS_IS_I8(fmt))
         B.thetai[s] = b > a ? (int)0x80000000 : 0x7FFFFFFF;
     else
@@ -960,9 +1014,9 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
                 uint16_t v = 0;
                 if (qi != 0xFFFFFFFFu) {
                     if (k < HVS_NDIM)
-                        v = hvs_bf16_bits(Q[(size_t)qi * HVS_QCOLS + 4 + k]);
+                        v = hvs_h16_bits(fmt, Q[(size_t)qi * HVS_QCOLS + 4 + k]);
                     else if (k < 103)
-                        v = 0x3F80;  // 1.0: multiplies the three -|d|^2/2 pieces
+                        v = fmt == HVS_FMT_F16 ? 0x3C00 : 0x3F80;  // 1.0: multiplies the three -|d|^2/2 pieces
                 }
                 v2[e2] = v;
             }
@@ -1286,6 +1340,29 @@ struct HvsFmt<HVS_FMT_BF16> {
     static __device__ __forceinline__ acc_t mfma(const frag_t& a, const frag_t& b, const acc_t& c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ thr_t max2(thr_t a, thr_t b) { return fmaxf(a, b); }
+};
+typedef _Float16 hvs_f16x8 __attribute__((ext_vector_type(8)));
+template <>
+struct HvsFmt<HVS_FMT_F16> {
+    static constexpr int KSTEPS = HVS_KSTEPS;
+    static constexpr int KMEM = HVS_KSTEPS;
+    typedef hvs_f16x8 frag_t;
+    typedef hvs_f32x16 acc_t;
+    typedef float thr_t;
+    static __device__ __forceinline__ frag_t frag(const uint4& u)
+    {
+        union {
+            uint4 u4;
+            hvs_f16x8 h8;
+        } c;
+        c.u4 = u;
+        return c.h8;
+    }
+    static __device__ __forceinline__ acc_t mfma(const frag_t& a, const frag_t& b, const acc_t& c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ thr_t max2(thr_t a, thr_t b) { return fmaxf(a, b); }
 };
@@ -2445,8 +2522,9 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                 if (cut) {
                     const double g = 20.0 * 5.9604644775390625e-08;
                     const double iu = qz->inv_sd * qz->inv_sd;  // 1 / sd^2
-                    const double band = ((double)B.nqb[slot] * (double)bounds->e_d8 + (double)B.eq[slot] * (double)bounds->n_d8) *
-                                        (1.0 + 1e-6);
+                    // (normq: the clip term of a query outside the data's box, see hvs_k_prep_slots)
+                    const double band = ((double)B.nqb[slot] * (double)bounds->e_d8 + (double)B.eq[slot] * (double)bounds->n_d8 +
+                                         (double)B.normq[slot]) * (1.0 + 1e-6);
                     // -2: one unit for nh = floor(.), one for the f64 evaluation of this expression (relative
                     // 1e-9 of the magnitudes on top)
                     double th = (0.5 * (B.qn[slot] * (1.0 - 1e-12) - (double)tau * (1.0 + 2.0 * g)) - band) * iu;
@@ -2510,6 +2588,16 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
         out_ids[(size_t)qi * knn + rank] = hvs_key_id(ke);
         if (out_dists) out_dists[(size_t)qi * knn + rank] = ke == ~0ull ? __builtin_inff() : hvs_key_dist(ke);
     }
+}
+
+// planner probe: rows of D as type-0 queries (every `step`-th row from step / 2)
+__global__ void hvs_k_probe_queries(const float* __restrict__ D, uint32_t n, uint32_t step, uint32_t count, float* __restrict__ Q)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count * HVS_QCOLS) return;
+    const uint32_t i = e / HVS_QCOLS, col = e % HVS_QCOLS;
+    const uint64_t row = ((uint64_t)i * step + step / 2u) % n;
+    Q[e] = col == 0u ? 0.0f : (col < 4u ? -1.0f : D[row * HVS_DCOLS + (col - 2u)]);
 }
 
 // queries this batch did not answer -> appended to the call's lists: HVS_FAIL_EXACT for the exact engine, HVS_FAIL_RETRY

@@ -14,7 +14,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_CSRC, "libhvs.so")
 _HDR = os.path.join(_REPO, "include", "hvs.h")
 
-ENGINE_AUTO, ENGINE_EXACT_SCAN, ENGINE_MFMA_FILTER, ENGINE_MFMA_I8 = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_EXACT_SCAN, ENGINE_MFMA_FILTER, ENGINE_MFMA_I8, ENGINE_MFMA_F16 = 0, 1, 2, 3, 4
 K, DCOLS, QCOLS = 100, 102, 104
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]

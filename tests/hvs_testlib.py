@@ -23,6 +23,7 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 DCOLS, QCOLS, K = 102, 104, 100
 GEN_V0, GEN_V1 = 0, 1
+GEN_CLUSTER, GEN_PCA, GEN_HEAVY = 2, 3, 4           # non-uniform vector laws (include/hvs_gen.h)
 SEED_DATA, SEED_QUERY = 0xD47A5EED, 0x9E3779B9
 
 _f32p = C.POINTER(C.c_float)
@@ -187,11 +188,41 @@ def _affine(u, scale, lo):
     return (np.float32(scale) * u).astype(np.float32) + np.float32(lo)
 
 
+def _bell(seed, rows, cols):
+    """hvs_gen_bell: Irwin-Hall(4) scaled to unit variance, the same f32 operations in the same order."""
+    us = [_u01(_u24((seed + o) & 0xFFFFFFFFFFFFFFFF, rows, cols)) for o in (0, 0x1234567, 0x2468ACE, 0x369D035)]
+    a = us[0] + us[1]
+    b = us[2] + us[3]
+    return ((a + b) - np.float32(2.0)) * np.float32(1.7320508)
+
+
+def _vec_numpy(seed, profile, rows):
+    """hvs_gen_vec_elem for all 100 components of `rows` (non-uniform profiles)."""
+    cols = np.arange(2, 102)
+    k = np.arange(100, dtype=np.uint32)
+    if profile == GEN_CLUSTER:
+        with np.errstate(over="ignore"):
+            base = _mix64(np.array([seed], np.uint64))[0]
+            cl = _mix64(base ^ (rows.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))) % np.uint64(64)
+        centre_tab = _affine(_u01(_u24(SEED_DATA ^ 0xC1057E5, np.arange(64, dtype=np.uint64), cols)), 9.0, -4.5)
+        return centre_tab[cl.astype(np.int64)] + (np.float32(0.6) * _bell(seed, rows, cols)).astype(np.float32)
+    if profile == GEN_PCA:
+        w = (32 - (k & 15)).astype(np.float32) * np.float32(0.03125)
+        wk = w * np.float32(0.5) ** (k >> 4).astype(np.float32)
+        return ((np.float32(6.0) * wk).astype(np.float32)[None, :] * _bell(seed, rows, cols)).astype(np.float32)
+    v = _u01(_u24((seed + 0x51ED270) & 0xFFFFFFFFFFFFFFFF, rows, np.array([127])))[:, 0]
+    v2 = v * v
+    r = np.float32(1.0) + np.float32(15.0) * (v2 * v2)
+    return (_affine(_u01(_u24(seed, rows, cols)), 3.0, -1.5) * r[:, None]).astype(np.float32)
+
+
 def gen_data_numpy(n, seed=SEED_DATA, profile=GEN_V1, ncat=100, row0=0):
     rows = np.arange(row0, row0 + n, dtype=np.uint64)
     u = _u24(seed, rows, np.arange(DCOLS))
     out = _affine(_u01(u), 12.0, -6.0)
-    if profile == GEN_V1:
+    if profile >= GEN_CLUSTER:
+        out[:, 2:] = _vec_numpy(seed, profile, rows)
+    if profile != GEN_V0:
         out[:, 0] = (u[:, 0] % np.uint32(ncat)).astype(np.float32)
         out[:, 1] = _u01(u[:, 1])
     else:
@@ -208,7 +239,18 @@ def gen_queries_numpy(nq, seed=SEED_QUERY, profile=GEN_V1, ncat=100, force_type=
     out[:, 0] = typ.astype(np.float32)
     has_c = (typ & 1) != 0
     has_t = (typ & 2) != 0
-    if profile == GEN_V1:
+    if profile >= GEN_CLUSTER:
+        with np.errstate(over="ignore"):
+            base = _mix64(np.array([(seed + 0x0B0F) & 0xFFFFFFFFFFFFFFFF], np.uint64))[0]
+            outlier = (_mix64(base + rows) % np.uint64(100)) == 0
+        vec = _vec_numpy(seed, profile, rows)
+        pushed = vec * np.float32(1.15)
+        w3 = (32 - np.arange(3)).astype(np.float32) * np.float32(0.03125)
+        far = {GEN_CLUSTER: np.full(3, 7.25, np.float32), GEN_PCA: (np.float32(23.0) * w3).astype(np.float32),
+               GEN_HEAVY: np.full(3, 26.5, np.float32)}[profile]
+        pushed[:, :3] = np.where((u[:, 4:7] & np.uint32(1)) != 0, far[None, :], -far[None, :])
+        out[:, 4:] = np.where(outlier[:, None], pushed, vec)
+    if profile != GEN_V0:
         v = (u[:, 1] % np.uint32(ncat)).astype(np.float32)
         l = _u01(u[:, 2])
         hi = np.float32(1.0)
