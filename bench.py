@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--force-type", type=int, default=-1, help="-1 mixed types, 0..3 a single type")
     ap.add_argument("--profile", type=int, default=1,
                     help="vector law of D and Q (include/hvs_gen.h): 1 gen-v1 uniform (the headline), 2 clustered, 3 PCA-like "
-                         "decaying variances, 4 heavy-tailed norms; 2-4: 1 %% of the queries lie outside the data's box")
+                         "decaying variances, 4 heavy-tailed norms, 5 gen-v1; 2-5: 1 %% of the queries lie outside the data's box")
     ap.add_argument("--cpu-seconds", type=float, default=60.0,
                     help="time cap of the CPU baseline leg (0 = skip): it times the fixed --cpu-queries prefix in chunks "
                          "of 256 queries and stops at the first chunk boundary past the cap")
@@ -113,7 +113,7 @@ def main():
             if gather_done[b & 1] is not None:
                 gather_done[b & 1].synchronize()                       # (two steps old: long done; keeps the buffer reuse honest)
             eng.export_results_device(b * a.batch, a.batch, buf.data_ptr())
-            eng.sync()                                                 # the block is complete (one host wait per step)
+            eng.stream_wait(torch.cuda.current_stream().cuda_stream)   # stream-ordered hand-off to the collective's stream
             dist.gather(buf, gathered, dst=0)                          # RCCL, asynchronous on torch's stream
             gather_done[b & 1] = torch.cuda.Event()
             gather_done[b & 1].record()
@@ -164,7 +164,7 @@ def main():
         value = nq_total / elapsed
         flops_alg = 200.0 * pairs                                      # 2*100 per passing pair
         k_s = kern_ms / 1e3
-        peak = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
+        peak = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS, 4: BF16_PEAK_TFLOPS}.get(engine_id, FP32_PEAK_TFLOPS)
         assert untimed == 0, "some launches of the dominant kernel were not timed: no roofline from this run"
         achieved = flops_alg / k_s / 1e12 if k_s > 0 else 0.0
         traffic = None
@@ -183,16 +183,17 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"D={a.n} rows x dim 100 replicated per GPU; step = {a.batch} "
                                    f"{'mixed-type' if a.force_type < 0 else 'type-%d' % a.force_type} queries per GPU "
-                                   f"from the {['gen-v0', 'gen-v1', 'clustered', 'PCA-like', 'heavy-tailed'][a.profile]} 4x10^6-query stream, "
+                                   f"from the {['gen-v0', 'gen-v1', 'clustered', 'PCA-like', 'heavy-tailed', 'gen-v1 + 1 % out-of-box'][a.profile]} 4x10^6-query stream, "
                                    f"k=100, sample_proportion=1",
                        "profile": a.profile,
                        "n": a.n, "queries_per_step_per_gpu": a.batch, "engine": engine_id,
                        "sharding": "Q partitioned across ranks, D replicated, RCCL gather of the ids to rank 0"},
-            "roofline": {"bound": "mfma" if engine_id in (2, 3) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma" if engine_id in (2, 3, 4) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": {2: "hvs_k_filter_mfma<bf16>",
+                         "kernel": {2: "hvs_k_filter_mfma<bf16>", 4: "hvs_k_filter_mfma<f16>",
                                     3: "hvs_k_filter_mfma<int8>" if os.environ.get("HVS_I8_SHAPE") == "32" else "hvs_k_filter_i8x16"}.get(engine_id, "hvs_k_scan_exact"),
-                         "peak_is": {2: "dense BF16 MFMA", 3: "dense INT8 MFMA (integer ops)"}.get(engine_id, "FP32 vector"),
+                         "peak_is": {2: "dense BF16 MFMA", 3: "dense INT8 MFMA (integer ops)",
+                                     4: "dense FP16 MFMA (= the BF16 rate)"}.get(engine_id, "FP32 vector"),
                          "kernel_ms_avg": kern_ms / max(kern_launches, 1), "launches": kern_launches,
                          "pairs_per_launch": pairs / max(kern_launches, 1),
                          "evaluated_pairs_per_launch": scanned / max(kern_launches, 1),
@@ -209,7 +210,7 @@ def main():
                          # context, not the peak: what the filter-shaped loop (LDS fragment reads, epilogue, 2 waves/SIMD)
                          # sustains on random operands on this chip: scripts/mfma_shape_lab.hip, 12.8 G 32x32 pair blocks/s
                          # x 262144 op (INT8 16x16x64); BF16: scripts/mfma_loop_lab.hip
-                         "measured_loop_ceiling_random_operands_tflops": {2: 1592.0, 3: 3350.0}.get(engine_id),
+                         "measured_loop_ceiling_random_operands_tflops": {2: 1592.0, 3: 3350.0, 4: 1592.0}.get(engine_id),
                          # bare in-place chains of the same instruction, 2 waves/SIMD (scripts/mfma_shape_lab.hip part 3)
                          "measured_bare_chain_ceiling_random_operands_tflops": {3: 4010.0}.get(engine_id),
                          "fallback_queries": fallback, "retry_queries": retried},
@@ -249,7 +250,7 @@ def main():
     # set), which an N-GPU run cuts into shares of 4x10^6 / N.  Each share is run on this GPU the way a rank would run it:
     # resident (one hvs_query_resident call) and from host memory (one hvs_query call, pageable buffers).
     if rank == 0 and world == 1 and not a.no_fixed_q and a.n == 10_000_000 and a.profile == 1:
-        peak_fq = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS}.get(engine_id, FP32_PEAK_TFLOPS)
+        peak_fq = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS, 4: BF16_PEAK_TFLOPS}.get(engine_id, FP32_PEAK_TFLOPS)
         fixed = {"query_set": 4_000_000, "note": "one GPU running the share a rank of an N-GPU run gets (D replicated); "
                  "whole-node rate of such a run = N x the share's rate if every rank does the same", "shares": []}
         for n_ranks in (1, 2, 4, 8):

@@ -162,6 +162,11 @@ int hvs_download_results(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *out_i
 /* Copy result rows [q0,q0+nq) into caller-owned DEVICE buffers (same GPU), e.g. a collective's
  * send buffer.  d_dists may be NULL.  Asynchronous on the context stream.  Single-GPU contexts only. */
 int hvs_export_results_device(hvs_ctx *ctx, uint32_t q0, uint32_t nq, uint32_t *d_ids, float *d_dists);
+/* Stream-ordered hand-off: work enqueued on `stream` (a hipStream_t of the context's GPU, e.g. the stream a collective
+ * runs on) after this call starts only when everything the context has enqueued so far is complete -- no host wait for
+ * the kernels (queries the filter left unanswered are re-run first, which costs the call's one host synchronisation).
+ * Single-GPU contexts only. */
+int hvs_stream_wait(hvs_ctx *ctx, void *stream);
 /* D-sharded mode (rows partitioned over GPUs, every GPU answers all queries on its rows with hvs_set_padding(ctx, 0)):
  * merges the shards' partial answers on the device -- the multi-GPU counterpart of Knn::merge (reference
  * include/optimized_impl.h:337-385) -- and applies the reference's padding (optimized_parallel.hpp:149-157) once.

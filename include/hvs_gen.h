@@ -33,7 +33,8 @@
  *   HVS_GEN_HEAVY    heavy-tailed row norms: x_k = 1.5 (2u - 1) r, r = 1 + 15 v^4 with ONE v in [0,1) per row (most
  *                    rows r ~ 1, one in 10^4 above 11).
  *   Queries follow the law of the data set (with their own seed); one query in 100 (hash of the row number) lies
- *   outside the data's bounding box: its first three coordinates are 10 % beyond the law's support, the rest scaled by 1.15.
+ *   outside the data's bounding box: its first three coordinates are 10 % beyond the law's support.
+ *   HVS_GEN_V1_OUT   HVS_GEN_V1 data and queries, with the same 1 % of out-of-box queries (first three coordinates +-6.625).
  *
  * All float arithmetic below is single operations on f32 values (no FMA
  * contraction allowed: build with -ffp-contract=off).
@@ -59,6 +60,7 @@
 #define HVS_GEN_CLUSTER 2
 #define HVS_GEN_PCA 3
 #define HVS_GEN_HEAVY 4
+#define HVS_GEN_V1_OUT 5   /* HVS_GEN_V1 whose queries include 1 % outside the data's box */
 #define HVS_GEN_NCLUSTERS 64u
 
 #define HVS_SEED_DATA 0xD47A5EEDull
@@ -150,7 +152,7 @@ HVS_HD float hvs_gen_data_elem(uint64_t seed, int profile, uint32_t ncat, uint64
         return profile != HVS_GEN_V0 ? (float)(u % ncat) : hvs_affine(hvs_u01(u), 2.0f, -1.0f);
     if (col == 1u)
         return profile != HVS_GEN_V0 ? hvs_u01(u) : hvs_affine(hvs_u01(u), 6.0f, -3.0f);
-    if (profile >= HVS_GEN_CLUSTER) return hvs_gen_vec_elem(seed, HVS_SEED_DATA, profile, row, col - 2u);
+    if (profile >= HVS_GEN_CLUSTER && profile <= HVS_GEN_HEAVY) return hvs_gen_vec_elem(seed, HVS_SEED_DATA, profile, row, col - 2u);
     return hvs_affine(hvs_u01(u), 12.0f, -6.0f);
 }
 
@@ -175,18 +177,18 @@ HVS_HD float hvs_gen_query_elem(uint64_t seed, int profile, uint32_t ncat, int f
         const float t = hvs_u01(u) * span;
         return l + t;
     }
-    if (profile >= HVS_GEN_CLUSTER) {
+    if (profile >= HVS_GEN_CLUSTER && profile <= HVS_GEN_HEAVY) {
         /* the law of the data set (cluster centres of HVS_SEED_DATA), the query's own draw; 1 % pushed outside the box */
         const uint32_t k = col - 4u;
         const float x = hvs_gen_vec_elem(seed, HVS_SEED_DATA, profile, row, k);
-        if (!hvs_gen_query_is_outlier(seed, row)) return x;
-        if (k >= 3u) return x * 1.15f;
+        if (k >= 3u || !hvs_gen_query_is_outlier(seed, row)) return x;
         /* the first three coordinates 10 % beyond anything the law can produce (7.25 / 23 w_k / 26.5 are above 1.1 x
          * the laws' supports 6.58 / 20.8 w_k / 24), so the query is certainly outside the data's box */
         const float w = (float)(32u - k) * 0.03125f;
         const float far = profile == HVS_GEN_CLUSTER ? 7.25f : (profile == HVS_GEN_PCA ? 23.0f * w : 26.5f);
         return (u & 1u) ? far : -far;
     }
+    if (profile == HVS_GEN_V1_OUT && col < 7u && hvs_gen_query_is_outlier(seed, row)) return (u & 1u) ? 6.625f : -6.625f;
     return hvs_affine(hvs_u01(u), 12.0f, -6.0f);
 }
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,8 @@
 #include <thread>
 #include <type_traits>
 #include <vector>
+
+#include <sched.h>
 
 #include <rocprim/rocprim.hpp>
 
@@ -131,6 +134,7 @@ struct hvs_ctx {
     // multi-GPU root (hvs_create_multi): owns one leaf context per GPU; D is replicated, the queries of a call are cut
     // into one contiguous range per leaf (optimized_parallel.hpp:91: iterations are independent) and every leaf
     // writes its block of ids straight into its slice of the caller's buffer
+    std::vector<int> node_cpus;  // CPUs of the NUMA node this GPU hangs off (empty: unknown); the leaf's host thread runs there
     std::vector<hvs_ctx*> kids;
     std::vector<uint32_t> kid_q0;  // resident queries: first global index of each leaf's range (kids.size() + 1 entries)
     int gather_mode = 0;           // HVS_GATHER_DIRECT / HVS_GATHER_PEER
@@ -1110,6 +1114,30 @@ int resolve_overflow(hvs_ctx* c)
     return HVS_OK;
 }
 
+// Host copy between pageable and pinned memory.  One thread moves ~10 GB/s; the first batch's queries and the last
+// batch's results of a call sit on the critical path (nothing computes under them), so pieces of 4 MB and more are cut
+// over up to 4 threads.
+void staging_copy(void* dst, const void* src, size_t bytes)
+{
+    static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned parts = bytes >= (4u << 20) ? std::min(4u, std::max(1u, hw / 4u)) : 1u;
+    if (parts <= 1u) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t chunk = ((bytes / parts) + 4095u) & ~(size_t)4095u;
+    std::vector<std::thread> th;
+    th.reserve(parts - 1u);
+    for (unsigned p = 1; p < parts; ++p) {
+        const size_t off = (size_t)p * chunk;
+        if (off >= bytes) break;
+        const size_t len = std::min(chunk, bytes - off);
+        th.emplace_back([=]() { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+    }
+    std::memcpy(dst, src, std::min(chunk, bytes));
+    for (auto& t : th) t.join();
+}
+
 // Batch schedule of one call (sizes in queries, in order).  Resident runs and the exact engines cut the call into
 // full batches.  `host_pipeline` (hvs_query): the first batch's queries and the last batch's results are the only
 // transfers the pipeline cannot hide, so those two batches are small (kBatchMfma / 8) once the call is large enough to
@@ -1118,8 +1146,10 @@ int resolve_overflow(hvs_ctx* c)
 std::vector<uint32_t> batch_schedule(uint32_t nq, uint32_t step, bool ramp_allowed)
 {
     std::vector<uint32_t> out;
-    const uint32_t edge = kBatchMfma / 8u;
-    const bool ramp = ramp_allowed && edge >= 1024u && nq >= 4u * edge;
+    // (calls of 2^17 .. 2^21 queries -- e.g. one GPU's share of BASELINE configs[3] on an 8-GPU node, 5 x 10^5 -- ramp too,
+    // with edges of an eighth of the call)
+    const uint32_t edge = std::min(kBatchMfma / 8u, std::max(16384u, hvs_ceil_div(nq / 8u, 512u) * 512u));
+    const bool ramp = ramp_allowed && edge >= 1024u && nq >= 131072u && nq >= 4u * edge;
     if (!ramp) {
         for (uint32_t off = 0; off < nq; off += step) out.push_back(std::min(step, nq - off));
         return out;
@@ -1434,7 +1464,7 @@ int upload_rows(hvs_ctx* c, float* dst, const float* src, size_t nfloats)
         const int k = i % hvs_ctx::kRing;
         const size_t m = std::min(slot, nfloats - off);
         if (i >= hvs_ctx::kRing) HVS_HIP(c, hipEventSynchronize(c->ev_in[k]));  // the slot's previous DMA is done
-        std::memcpy(c->h_in[k], src + off, m * sizeof(float));
+        staging_copy(c->h_in[k], src + off, m * sizeof(float));
         HVS_HIP(c, hipMemcpyAsync(dst + off, c->h_in[k], m * sizeof(float), hipMemcpyHostToDevice, c->s_in));
         HVS_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
     }
@@ -1442,7 +1472,8 @@ int upload_rows(hvs_ctx* c, float* dst, const float* src, size_t nfloats)
     return HVS_OK;
 }
 
-int leaf_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+// upload only (the multi-GPU root lets the other GPUs copy D from this one while it builds its index)
+int leaf_upload_data(hvs_ctx* c, const float* rows, uint32_t n)
 {
     int rc = begin_data(c, n);
     if (rc) return rc;
@@ -1451,6 +1482,13 @@ int leaf_load_data(hvs_ctx* c, const float* rows, uint32_t n)
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->n = n;
+    return HVS_OK;
+}
+
+int leaf_load_data(hvs_ctx* c, const float* rows, uint32_t n)
+{
+    int rc = leaf_upload_data(c, rows, n);
+    if (rc) return rc;
     return finish_data(c);
 }
 
@@ -1546,18 +1584,30 @@ int leaf_download_results(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* out_id
 //                    the calling thread drains the slots into the caller's arrays
 // Buffers the caller pinned itself (hipHostMalloc / hipHostRegister) skip the staging copies.  Overflowed queries
 // (rare) are re-run at the end and their rows fetched again.
-int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids, float* out_dists)
+// `sink` (HVS_GATHER_PEER): finished pieces do not leave for the host but for GPU `sink->ctx`'s result buffer, rows
+// sink->row0 + ..., over xGMI (hipMemcpyPeerAsync on this GPU's copy-out stream, under the next batch's compute); the
+// root downloads the gathered block once every GPU is done.  out_ids / out_dists are then unused.
+struct PeerSink {
+    hvs_ctx* ctx;
+    uint32_t row0;
+    bool want_dists;
+};
+
+int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids, float* out_dists,
+               const PeerSink* sink = nullptr)
 {
     if (!c->d_data) return fail(c, HVS_ESTATE, "no data set loaded (hvs_load_data / hvs_gen_data)");
     if (nq == 0) return HVS_OK;
-    if (!q_rows || !out_ids) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
+    if (!q_rows || (!out_ids && !sink)) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
     const auto t_host0 = std::chrono::steady_clock::now();
     int rc = leaf_begin_queries(c, nq);
     if (rc) return rc;
-    if ((rc = ensure_staging(c, out_dists != nullptr))) return rc;
+    if ((rc = ensure_staging(c, out_dists != nullptr && !sink))) return rc;
     c->nq = nq;
     const bool in_pinned = host_pointer_is_pinned(q_rows);
-    const bool out_pinned = host_pointer_is_pinned(out_ids) && (!out_dists || host_pointer_is_pinned(out_dists));
+    // (a peer sink behaves like a pinned destination: asynchronous copies straight from the result buffer, nothing to drain)
+    const bool out_pinned = sink || (host_pointer_is_pinned(out_ids) && (!out_dists || host_pointer_is_pinned(out_dists)));
+    const bool sink_dists = sink && sink->want_dists;
     constexpr uint32_t SQ = hvs_ctx::kStageQ;
     constexpr int R = hvs_ctx::kRing;
     const uint32_t npieces = hvs_ceil_div(nq, SQ);
@@ -1574,7 +1624,7 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
             } else {
                 const int k = (int)(in_next % R);
                 if (in_next >= (uint32_t)R) HVS_HIP(c, hipEventSynchronize(c->ev_in[k]));
-                std::memcpy(c->h_in[k], q_rows + (size_t)q0 * HVS_QCOLS, bytes);
+                staging_copy(c->h_in[k], q_rows + (size_t)q0 * HVS_QCOLS, bytes);
                 HVS_HIP(c, hipMemcpyAsync(dst, c->h_in[k], bytes, hipMemcpyHostToDevice, c->s_in));
                 HVS_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
             }
@@ -1587,8 +1637,8 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         const int k = (int)(out_drained % R);
         HVS_HIP(c, hipEventSynchronize(c->ev_out[k]));
         const uint32_t q0 = out_drained * SQ, m = std::min(SQ, nq - q0);
-        std::memcpy(out_ids + (size_t)q0 * c->k, c->h_out_ids[k], (size_t)m * c->k * sizeof(uint32_t));
-        if (out_dists) std::memcpy(out_dists + (size_t)q0 * c->k, c->h_out_dists[k], (size_t)m * c->k * sizeof(float));
+        staging_copy(out_ids + (size_t)q0 * c->k, c->h_out_ids[k], (size_t)m * c->k * sizeof(uint32_t));
+        if (out_dists) staging_copy(out_dists + (size_t)q0 * c->k, c->h_out_dists[k], (size_t)m * c->k * sizeof(float));
         ++out_drained;
         return HVS_OK;
     };
@@ -1596,6 +1646,14 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         for (; out_enq < p1; ++out_enq) {
             const uint32_t q0 = out_enq * SQ, m = std::min(SQ, nq - q0);
             const size_t nb = (size_t)m * c->k * sizeof(uint32_t);
+            if (sink) {
+                const size_t dst = ((size_t)sink->row0 + q0) * c->k;
+                HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_ids + dst, sink->ctx->device, c->d_out_ids + (size_t)q0 * c->k, c->device, nb, c->s_out));
+                if (sink_dists)
+                    HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_dists + dst, sink->ctx->device, c->d_out_dists + (size_t)q0 * c->k, c->device, nb,
+                                                  c->s_out));
+                continue;
+            }
             if (out_pinned) {
                 HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)q0 * c->k, c->d_out_ids + (size_t)q0 * c->k, nb, hipMemcpyDeviceToHost, c->s_out));
                 if (out_dists)
@@ -1664,6 +1722,15 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         if (nretry)
             HVS_HIP(c, hipMemcpy(list.data() + novf, c->d_retry_list, (size_t)nretry * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t qi : list) {
+            if (sink) {
+                const size_t dst = ((size_t)sink->row0 + qi) * c->k;
+                HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_ids + dst, sink->ctx->device, c->d_out_ids + (size_t)qi * c->k, c->device,
+                                              c->k * sizeof(uint32_t), c->stream));
+                if (sink_dists)
+                    HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_dists + dst, sink->ctx->device, c->d_out_dists + (size_t)qi * c->k,
+                                                  c->device, c->k * sizeof(float), c->stream));
+                continue;
+            }
             HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * c->k, c->d_out_ids + (size_t)qi * c->k, c->k * sizeof(uint32_t),
                                       hipMemcpyDeviceToHost, c->stream));
             if (out_dists)
@@ -1716,6 +1783,52 @@ void shard_range(uint32_t total, uint32_t r, uint32_t world, uint32_t& a, uint32
     b = a + base + (r < rem ? 1u : 0u);
 }
 
+// CPUs of the NUMA node of a GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<k>/cpulist
+// (best effort: empty when the platform does not say)
+std::vector<int> device_node_cpus(int device)
+{
+    std::vector<int> cpus;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return cpus;
+    }
+    for (char* p = bus; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+    int node = -1;
+    if (FILE* f = std::fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return cpus;
+    if (FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        int a = 0, b = 0;
+        for (;;) {  // "0-15,128-143"
+            if (std::fscanf(f, "%d", &a) != 1) break;
+            b = a;
+            int ch = std::fgetc(f);
+            if (ch == '-') {
+                if (std::fscanf(f, "%d", &b) != 1) break;
+                ch = std::fgetc(f);
+            }
+            for (int x = a; x <= b && x < CPU_SETSIZE; ++x) cpus.push_back(x);
+            if (ch != ',') break;
+        }
+        std::fclose(f);
+    }
+    return cpus;
+}
+
+// the calling thread (one leaf's host thread: staging copies, launches) moves next to its GPU; helper threads it starts
+// inherit the mask
+void pin_to_node(const hvs_ctx* leaf)
+{
+    if (leaf->node_cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int x : leaf->node_cpus) CPU_SET(x, &set);
+    (void)sched_setaffinity(0, sizeof(set), &set);
+}
+
 // run fn(leaf index) on one host thread per leaf (the reference's vec_query owns its worker threads the same way,
 // optimized_parallel.hpp:82-89, threading.hpp:100-141) and return the first failure
 template <typename Fn>
@@ -1728,7 +1841,11 @@ int for_each_leaf(hvs_ctx* root, Fn fn)
     } else {
         std::vector<std::thread> th;
         th.reserve(N);
-        for (size_t r = 0; r < N; ++r) th.emplace_back([&, r]() { rcs[r] = fn((uint32_t)r); });
+        for (size_t r = 0; r < N; ++r)
+            th.emplace_back([&, r]() {
+                pin_to_node(root->kids[r]);  // (threads of this call only: the caller's own thread keeps its affinity)
+                rcs[r] = fn((uint32_t)r);
+            });
         for (auto& t : th) t.join();
     }
     for (size_t r = 0; r < N; ++r)
@@ -1790,6 +1907,7 @@ int hvs_create_on_devices(hvs_ctx** out, const int* devices, int n)
             hvs_destroy(root);
             return rc;
         }
+        if (n > 1 && env_u32("HVS_NUMA_PIN", 1u, 0u, 1u)) leaf->node_cpus = device_node_cpus(devices[i]);
         root->kids.push_back(leaf);
     }
     // peer access lets the replication of D and the peer gather use xGMI directly (best effort: without it the
@@ -1938,11 +2056,17 @@ int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
     if (!c) return HVS_EINVAL;
     if (!rows) return fail(c, HVS_EINVAL, "hvs_load_data: rows is NULL");
     if (c->kids.empty()) return leaf_load_data(c, rows, n);
-    // one upload over PCIe, then every other GPU takes its copy of D from the first over xGMI and builds its own index
-    int rc = leaf_load_data(c->kids[0], rows, n);
+    // one upload over PCIe; then, at the same time, the first GPU builds its index and every other GPU takes its copy of D
+    // from the first over xGMI (each pair has its own link) and builds its own
+    int rc = leaf_upload_data(c->kids[0], rows, n);
     if (rc) return fail(c, rc, c->kids[0]->err);
-    if (c->kids.size() == 1) return HVS_OK;
-    return for_each_leaf(c, [&](uint32_t r) { return r == 0u ? HVS_OK : leaf_load_data_from_peer(c->kids[r], c->kids[0]); });
+    return for_each_leaf(c, [&](uint32_t r) {
+        if (r == 0u) {
+            HVS_HIP(c->kids[0], hipSetDevice(c->kids[0]->device));
+            return finish_data(c->kids[0]);
+        }
+        return leaf_load_data_from_peer(c->kids[r], c->kids[0]);
+    });
 }
 
 int hvs_gen_data(hvs_ctx* c, uint32_t n, uint64_t seed, int profile, uint32_t ncat)
@@ -2056,6 +2180,18 @@ int hvs_export_results_device(hvs_ctx* c, uint32_t q0, uint32_t nq, uint32_t* d_
     return HVS_OK;
 }
 
+int hvs_stream_wait(hvs_ctx* c, void* stream)
+{
+    if (!c) return HVS_EINVAL;
+    if (!c->kids.empty()) return fail(c, HVS_EINVAL, "hvs_stream_wait: single-GPU contexts only (a stream belongs to one GPU)");
+    HVS_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_overflow(c);
+    if (rc) return rc;
+    HVS_HIP(c, hipEventRecord(c->ev_batch, c->stream));
+    HVS_HIP(c, hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_batch, 0));
+    return HVS_OK;
+}
+
 int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proportion, uint32_t* out_ids,
               float* out_dists)
 {
@@ -2081,41 +2217,38 @@ int hvs_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_proport
                               out_dists ? out_dists + (size_t)a * c->k : nullptr);
         });
     } else {
-        // peer gather (A/B partner): every GPU answers its resident slice, the blocks of ids travel GPU -> GPU 0 over
-        // xGMI and leave in one D2H
-        rc = for_each_leaf(c, [&](uint32_t r) -> int {
-            const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
-            hvs_ctx* k = c->kids[r];
-            int r2 = leaf_upload_queries(k, q_rows + (size_t)a * HVS_QCOLS, r == 0u ? m : m);
-            if (r2) return r2;
-            if (r == 0u && (r2 = ensure_results(k, nq))) return r2;  // GPU 0 receives everybody's block
-            if (m == 0u) {
-                k->timing_valid = false;
-                return HVS_OK;
-            }
-            if ((r2 = run_queries(k, 0, m, sample_proportion, NoHook{}))) return r2;
-            return leaf_sync(k);
-        });
-        if (!rc) {
-            hvs_ctx* k0 = c->kids[0];
-            (void)hipSetDevice(k0->device);  // the copies are enqueued on GPU 0's stream
-            for (uint32_t r = 1; r < N && !rc; ++r) {
+        // peer gather (A/B partner of the direct path): every GPU runs the same host pipeline on its slice of the caller's
+        // queries, but its finished pieces travel GPU -> GPU 0 over xGMI under the next batch's compute (PeerSink) instead
+        // of going to the host; the gathered block leaves GPU 0 in one D2H.  GPU 0's own slice starts at row 0 of its
+        // result buffer, which holds everybody's rows.
+        hvs_ctx* k0 = c->kids[0];
+        (void)hipSetDevice(k0->device);
+        rc = ensure_results(k0, nq);
+        if (rc) rc = fail(c, rc, k0->err);
+        if (!rc)
+            rc = for_each_leaf(c, [&](uint32_t r) -> int {
                 const uint32_t a = c->kid_q0[r], m = c->kid_q0[r + 1] - a;
                 hvs_ctx* k = c->kids[r];
-                if (m == 0u) continue;
-                if (hipMemcpyPeerAsync(k0->d_out_ids + (size_t)a * c->k, k0->device, k->d_out_ids, k->device,
-                                       (size_t)m * c->k * sizeof(uint32_t), k0->stream) != hipSuccess ||
-                    (out_dists && hipMemcpyPeerAsync(k0->d_out_dists + (size_t)a * c->k, k0->device, k->d_out_dists, k->device,
-                                                     (size_t)m * c->k * sizeof(float), k0->stream) != hipSuccess))
-                    rc = fail(c, HVS_EHIP, "hvs_query: peer copy of a result block failed");
-            }
-            if (!rc) {
-                if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * c->k * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
-                    (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToHost,
-                                                 k0->stream) != hipSuccess) ||
-                    hipStreamSynchronize(k0->stream) != hipSuccess)
-                    rc = fail(c, HVS_EHIP, "hvs_query: download of the gathered results failed");
-            }
+                if (m == 0u) {
+                    k->timing_valid = false;
+                    return HVS_OK;
+                }
+                if (r == 0u) {  // its results are already where the gather wants them: plain resident run of its slice
+                    int r2 = leaf_upload_queries(k, q_rows, m);
+                    if (r2) return r2;
+                    if ((r2 = run_queries(k, 0, m, sample_proportion, NoHook{}))) return r2;
+                    return leaf_sync(k);
+                }
+                const PeerSink sink{k0, a, out_dists != nullptr};
+                return leaf_query(k, q_rows + (size_t)a * HVS_QCOLS, m, sample_proportion, nullptr, nullptr, &sink);
+            });
+        if (!rc) {
+            (void)hipSetDevice(k0->device);
+            if (hipMemcpyAsync(out_ids, k0->d_out_ids, (size_t)nq * c->k * sizeof(uint32_t), hipMemcpyDeviceToHost, k0->stream) != hipSuccess ||
+                (out_dists && hipMemcpyAsync(out_dists, k0->d_out_dists, (size_t)nq * c->k * sizeof(float), hipMemcpyDeviceToHost,
+                                             k0->stream) != hipSuccess) ||
+                hipStreamSynchronize(k0->stream) != hipSuccess)
+                rc = fail(c, HVS_EHIP, "hvs_query: download of the gathered results failed");
         }
     }
     c->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -7,6 +7,8 @@
 // (test.cpp:82-88: data already in host memory -> ids back in host memory), prints
 // "Vector Search took <ms> ms" on stderr (test.cpp:91-92), writes output.bin (io.h:23-36) and
 // <output>.dist with the scalar-order distances of the chosen rows (test.cpp:97-110, io.h:38-78).
+// k: the reference's KNN_LIMIT is a compile-time 100 (optimized_impl.h:26); HVS_K=<8..256> runs the driver with another k
+// (rows of output.bin / .dist then hold k entries).
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -14,6 +16,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hvs.h"
@@ -77,8 +80,17 @@ int main(int argc, char** argv)
         std::cerr << hvs_last_global_error() << "\n";
         return 3;
     }
+    uint32_t K = 100;
+    if (const char* e = std::getenv("HVS_K")) {
+        if (hvs_set_k(ctx, (uint32_t)std::atoi(e)) != HVS_OK) {
+            std::cerr << "HVS_K: " << hvs_last_error(ctx) << "\n";
+            hvs_destroy(ctx);
+            return 3;
+        }
+        K = hvs_get_k(ctx);
+    }
     (void)hvs_reserve(ctx, nq);
-    std::vector<uint32_t> ids((size_t)nq * 100);
+    std::vector<uint32_t> ids((size_t)nq * K);
     std::cout << "# data points:  " << n << "\n# data point dim:  102\n# queries:      " << nq << "\n";
     const auto t0 = std::chrono::steady_clock::now();
     int rc = hvs_load_data(ctx, nodes.data(), n);
@@ -104,24 +116,38 @@ int main(int argc, char** argv)
     std::fwrite(ids.data(), sizeof(uint32_t), ids.size(), f);
     std::fclose(f);
 
+    // .dist: one scalar-order distance per (query, neighbour) -- nq x k rows of D fetched at random (io.h:50-78 walks them
+    // one by one; at BASELINE configs[3] size that is 4 x 10^8 rows of 408 bytes, tens of seconds on one core): the
+    // queries are cut over the machine's cores, the file is written in order from the filled array
+    std::vector<float> dist((size_t)nq * K);
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nth = (unsigned)std::max<uint64_t>(1u, std::min<uint64_t>(hw, (uint64_t)nq / 256u));
+        auto work = [&](unsigned t) {
+            const uint32_t q0 = (uint32_t)((uint64_t)nq * t / nth), q1 = (uint32_t)((uint64_t)nq * (t + 1u) / nth);
+            for (uint32_t i = q0; i < q1; ++i) {
+                const float* b = &queries[(size_t)i * 104 + 4];
+                for (uint32_t k = 0; k < K; ++k) {
+                    const float* a = &nodes[(size_t)ids[(size_t)i * K + k] * 102];
+                    float sum = 0.0f;  // io.h:38-48 calc_dist: sequential order
+                    for (int x = 0; x < 100; ++x) {
+                        float diff = a[2 + x] - b[x];
+                        diff = diff * diff;
+                        sum = sum + diff;
+                    }
+                    dist[(size_t)i * K + k] = sum;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; ++t) th.emplace_back(work, t);
+        work(0u);
+        for (auto& t : th) t.join();
+    }
     f = std::fopen((knn_save_path + ".dist").c_str(), "wb");
     if (!f) return 2;
     std::fwrite(&nq, sizeof(uint32_t), 1, f);
-    std::vector<float> line(100);
-    for (uint32_t i = 0; i < nq; ++i) {
-        for (int k = 0; k < 100; ++k) {
-            const float* a = &nodes[(size_t)ids[(size_t)i * 100 + k] * 102];
-            const float* b = &queries[(size_t)i * 104 + 4];
-            float sum = 0.0f;  // io.h:38-48 calc_dist: sequential order
-            for (int x = 0; x < 100; ++x) {
-                float diff = a[2 + x] - b[x];
-                diff = diff * diff;
-                sum = sum + diff;
-            }
-            line[k] = sum;
-        }
-        std::fwrite(line.data(), sizeof(float), 100, f);
-    }
+    std::fwrite(dist.data(), sizeof(float), dist.size(), f);
     std::fclose(f);
     return 0;
 }

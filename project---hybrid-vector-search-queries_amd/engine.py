@@ -148,6 +148,7 @@ def library():
         "hvs_sync": (C.c_int, [vp]),
         "hvs_download_results": (C.c_int, [vp, C.c_uint32, C.c_uint32, _u32p, _f32p]),
         "hvs_export_results_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+        "hvs_stream_wait": (C.c_int, [vp, vp]),
         "hvs_merge_shards_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64), C.c_uint32, vp, vp, vp]),
         "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
         "hvs_last_reruns": (C.c_int, [vp, C.c_int, _u32p, C.c_uint32]),
@@ -301,6 +302,11 @@ class Engine:
         """Copy results into device buffers given as raw pointers (e.g. torch tensor.data_ptr())."""
         self._ck(self._lib.hvs_export_results_device(self._h, q0, nq, C.c_void_p(ids_ptr),
                                                      C.c_void_p(dists_ptr) if dists_ptr else None))
+
+    def stream_wait(self, stream_ptr):
+        """Work enqueued on the given hipStream_t (raw pointer, e.g. torch.cuda.current_stream().cuda_stream) from now on
+        waits for everything this context has enqueued so far -- a stream-ordered hand-off, no host wait for the kernels."""
+        self._ck(self._lib.hvs_stream_wait(self._h, C.c_void_p(stream_ptr)))
 
     def merge_shards_device(self, ids_all_ptr, dists_all_ptr, shard_row0, nq, n_total, pad_dists_ptr, out_ids_ptr,
                             out_dists_ptr=None):

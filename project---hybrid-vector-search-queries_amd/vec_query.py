@@ -16,12 +16,13 @@ from .engine import Engine, HvsError
 _engine_cache = {}
 
 
-def vec_query(nodes, queries, sample_proportion, knn_results, n_gpus=None):
+def vec_query(nodes, queries, sample_proportion, knn_results, n_gpus=None, k=100):
     """Drop-in for the reference's vec_query.  `nodes`: n x 102, `queries`: nq x 104 (sequences of
     rows or arrays).  Like the reference it reports nothing: preconditions are the caller's
     (n >= 100, full rows); unlike it, a violated precondition raises instead of reading out of
     bounds.  Like the reference, which sizes its own thread pool (optimized_parallel.hpp:73-78), the call
-    spreads over the node's GPUs: one per 32768 queries, at most all (`n_gpus` overrides)."""
+    spreads over the node's GPUs: one per 32768 queries, at most all (`n_gpus` overrides).  `k`: the reference's
+    compile-time KNN_LIMIT (optimized_impl.h:26), 8..256."""
     nodes = np.ascontiguousarray(nodes, np.float32)
     queries = np.ascontiguousarray(queries, np.float32)
     print(f"# data points:  {nodes.shape[0]}")
@@ -32,9 +33,11 @@ def vec_query(nodes, queries, sample_proportion, knn_results, n_gpus=None):
         have = max(1, int(library().hvs_device_count()))
         n_gpus = max(1, min(have, queries.shape[0] // 32768))
     with Engine(n_gpus=n_gpus) as eng:
+        if k != 100:
+            eng.set_k(k)
         eng.reserve(queries.shape[0])
         eng.load_data(nodes)
-        ids = eng.query(queries, sample_proportion, want_dists=False) if queries.shape[0] else np.empty((0, 100), np.uint32)
+        ids = eng.query(queries, sample_proportion, want_dists=False) if queries.shape[0] else np.empty((0, k), np.uint32)
     for row in ids:
         knn_results.append(row.tolist())
 
@@ -52,11 +55,11 @@ def ReadBin(file_path, num_dimensions):
     return data
 
 
-def SaveKNN(knns, path="output.bin"):
-    """io.h:23-36: nq x 100 uint32, no header."""
+def SaveKNN(knns, path="output.bin", k=100):
+    """io.h:23-36: nq x k uint32 (k = the reference's KNN_LIMIT, 100 unless the engine ran with another k), no header."""
     a = np.ascontiguousarray(knns, np.uint32)
-    if a.ndim != 2 or a.shape[1] != 100:
-        raise HvsError(-1, "SaveKNN expects nq x 100 ids")
+    if a.ndim != 2 or a.shape[1] != k:
+        raise HvsError(-1, f"SaveKNN expects nq x {k} ids")
     a.tofile(path)
 
 

@@ -24,6 +24,7 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 DCOLS, QCOLS, K = 102, 104, 100
 GEN_V0, GEN_V1 = 0, 1
 GEN_CLUSTER, GEN_PCA, GEN_HEAVY = 2, 3, 4           # non-uniform vector laws (include/hvs_gen.h)
+GEN_V1_OUT = 5                                        # gen-v1 with 1 % of the queries outside the data's box
 SEED_DATA, SEED_QUERY = 0xD47A5EED, 0x9E3779B9
 
 _f32p = C.POINTER(C.c_float)
@@ -220,7 +221,7 @@ def gen_data_numpy(n, seed=SEED_DATA, profile=GEN_V1, ncat=100, row0=0):
     rows = np.arange(row0, row0 + n, dtype=np.uint64)
     u = _u24(seed, rows, np.arange(DCOLS))
     out = _affine(_u01(u), 12.0, -6.0)
-    if profile >= GEN_CLUSTER:
+    if GEN_CLUSTER <= profile <= GEN_HEAVY:
         out[:, 2:] = _vec_numpy(seed, profile, rows)
     if profile != GEN_V0:
         out[:, 0] = (u[:, 0] % np.uint32(ncat)).astype(np.float32)
@@ -243,11 +244,11 @@ def gen_queries_numpy(nq, seed=SEED_QUERY, profile=GEN_V1, ncat=100, force_type=
         with np.errstate(over="ignore"):
             base = _mix64(np.array([(seed + 0x0B0F) & 0xFFFFFFFFFFFFFFFF], np.uint64))[0]
             outlier = (_mix64(base + rows) % np.uint64(100)) == 0
-        vec = _vec_numpy(seed, profile, rows)
-        pushed = vec * np.float32(1.15)
+        vec = _vec_numpy(seed, profile, rows) if profile <= GEN_HEAVY else out[:, 4:].copy()
+        pushed = vec.copy()
         w3 = (32 - np.arange(3)).astype(np.float32) * np.float32(0.03125)
         far = {GEN_CLUSTER: np.full(3, 7.25, np.float32), GEN_PCA: (np.float32(23.0) * w3).astype(np.float32),
-               GEN_HEAVY: np.full(3, 26.5, np.float32)}[profile]
+               GEN_HEAVY: np.full(3, 26.5, np.float32), GEN_V1_OUT: np.full(3, 6.625, np.float32)}[profile]
         pushed[:, :3] = np.where((u[:, 4:7] & np.uint32(1)) != 0, far[None, :], -far[None, :])
         out[:, 4:] = np.where(outlier[:, None], pushed, vec)
     if profile != GEN_V0:

@@ -608,8 +608,22 @@ def test_multi_gpu_context_virtual_ranks(engine):
             m.query_resident(4000, 2000, 1.0)     # outside the resident set
         with pytest.raises(PKG.HvsError):
             m.export_results_device(0, 10, 1)     # device pointers belong to one GPU
+        # another k, a sampled prefix of the rows, and the peer gather without distances
+        m.set_k(37)
+        with PKG.Engine(0) as one:
+            one.set_engine(engine)
+            one.set_k(37)
+            one.load_data(nodes)
+            want37 = one.query(queries, 0.6, want_dists=False)
+        for mode in (1, 0):
+            m.set_gather(mode)
+            got37 = m.query(queries, 0.6, want_dists=False)
+            assert got37.shape == (nq, 37) and np.array_equal(got37, want37), mode
     ref, _ = T.oracle_query(nodes, queries[:300])
     T.check_parity(nodes, queries[:300], ids1[:300], ref, got_dists=d1[:300])
+    with T.oracle_k(37):
+        ref37, _ = T.oracle_query(nodes, queries[:200], 0.6)
+        T.check_parity(nodes, queries[:200], want37[:200], ref37, sample_proportion=0.6)
 
 
 def test_host_pipeline_many_pieces_and_caller_buffers():
@@ -676,7 +690,7 @@ def test_host_path_stages_every_batch_it_runs(nq, devices):
     T.check_parity(nodes, queries[sel], want[sel], ref)
 
 
-@pytest.mark.parametrize("profile", [T.GEN_CLUSTER, T.GEN_PCA, T.GEN_HEAVY], ids=["clustered", "pca", "heavy_tails"])
+@pytest.mark.parametrize("profile", [T.GEN_CLUSTER, T.GEN_PCA, T.GEN_HEAVY, T.GEN_V1_OUT], ids=["clustered", "pca", "heavy_tails", "v1_out_of_box"])
 def test_nonuniform_vector_laws_parity(profile):
     """Non-uniform vector laws (include/hvs_gen.h; the reference's contest data is clustered / PCA-like, README.md:58-60)
     at n = 10^6, 1 % of the queries outside the data's bounding box: both filter engines bit-equal to the exact engine,
@@ -708,6 +722,8 @@ def test_nonuniform_vector_laws_parity(profile):
                 # the planner's probe picks a format whose band fits this data: (almost) nothing is left to the exact engine,
                 # out-of-box queries included
                 assert t.engine in FILTER_ENGINES and t.fallback_queries <= nq // 100, (t.engine, t.fallback_queries)
+                if profile == T.GEN_V1_OUT:   # uniform data: INT8 tiles, and a query outside the box pays a wider band only
+                    assert t.engine == PKG.ENGINE_MFMA_I8 and t.fallback_queries <= outside.sum() // 10
     sel = np.r_[np.nonzero(outside)[0][:24], 0:40]
     ref, _ = T.oracle_query(nodes, queries[sel], threads=8)
     T.check_parity(nodes, queries[sel], want_i[sel], ref, got_dists=want_d[sel])
@@ -807,7 +823,7 @@ def test_config3_host_path_4e6_queries_one_call():
 def test_d1e8_config4_hbm_sizing():
     """BASELINE configs[4], one GPU's view of it: D = 10^8 rows resident (40.8 GB of rows + the INT8 index), 2^18 mixed
     queries through HVS_ENGINE_AUTO: filter engine, no fallbacks, sorted distances, predicate / padding properties on
-    every answer, bit-equality with the exact-scan engine on 1024 queries and with the oracle on 8 queries per type."""
+    every answer, bit-equality with the exact-scan engine on 1024 queries and with the oracle on 32 queries per type."""
     n, nq = 100_000_000, 1 << 18
     with PKG.Engine(0) as e:
         e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
@@ -836,9 +852,9 @@ def test_d1e8_config4_hbm_sizing():
     assert np.all(((tt >= queries[has_t, 2:3]) & (tt <= queries[has_t, 3:4]))[notpad[has_t]])
     for row in ids[typ == 0][::997]:
         assert len(set(row.tolist())) == 100
-    pick = np.concatenate([np.nonzero(typ == k)[0][:8] for k in range(4)])
+    pick = np.concatenate([np.nonzero(typ == k)[0][:32] for k in range(4)])           # 128 queries against the oracle
     assert np.array_equal(T.oracle_dists_for_ids(nodes, queries[pick], ids[pick]).view(np.uint32), dists[pick].view(np.uint32))
-    ref, _ = T.oracle_query(nodes, queries[pick], threads=16)
+    ref, _ = T.oracle_query(nodes, queries[pick], threads=32)
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
 
 

@@ -35,7 +35,8 @@ def test_fp_known_answer():
 
 
 def test_generator_numpy_twin():
-    for profile, ncat in ((T.GEN_V1, 100), (T.GEN_V0, 7), (T.GEN_CLUSTER, 10), (T.GEN_PCA, 100), (T.GEN_HEAVY, 3)):
+    for profile, ncat in ((T.GEN_V1, 100), (T.GEN_V0, 7), (T.GEN_CLUSTER, 10), (T.GEN_PCA, 100), (T.GEN_HEAVY, 3),
+                          (T.GEN_V1_OUT, 100)):
         a = T.gen_data(777, 12345, profile, ncat, row0=5)
         b = T.gen_data_numpy(777, 12345, profile, ncat, row0=5)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
