@@ -1721,23 +1721,58 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         if (novf) HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (nretry)
             HVS_HIP(c, hipMemcpy(list.data() + novf, c->d_retry_list, (size_t)nretry * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint32_t qi : list) {
-            if (sink) {
+        if (sink) {
+            for (uint32_t qi : list) {
                 const size_t dst = ((size_t)sink->row0 + qi) * c->k;
                 HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_ids + dst, sink->ctx->device, c->d_out_ids + (size_t)qi * c->k, c->device,
                                               c->k * sizeof(uint32_t), c->stream));
                 if (sink_dists)
                     HVS_HIP(c, hipMemcpyPeerAsync(sink->ctx->d_out_dists + dst, sink->ctx->device, c->d_out_dists + (size_t)qi * c->k,
                                                   c->device, c->k * sizeof(float), c->stream));
-                continue;
             }
-            HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * c->k, c->d_out_ids + (size_t)qi * c->k, c->k * sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, c->stream));
-            if (out_dists)
-                HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)qi * c->k, c->d_out_dists + (size_t)qi * c->k,
-                                          c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HVS_HIP(c, hipStreamSynchronize(c->stream));
+        } else {
+            // the re-run rows are packed on the device (the idle candidate workspace is the scratch), leave in ONE copy and
+            // are scattered here: thousands of 400-byte copies cost ~10 us each
+            const size_t cnt = list.size(), words = cnt * c->k;
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(c->fb.cand);
+            const bool fits = scratch && 2u * words * sizeof(uint32_t) <= c->fb_cand_entries * sizeof(uint64_t);
+            if (fits) {
+                uint32_t* d_list = scratch + 2u * words;  // (the list itself rides behind the rows when there is room)
+                const bool list_fits = (2u * words + cnt) * sizeof(uint32_t) <= c->fb_cand_entries * sizeof(uint64_t);
+                uint32_t* d_list_tmp = nullptr;
+                if (!list_fits) {
+                    HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_list_tmp), cnt * sizeof(uint32_t)));
+                    d_list = d_list_tmp;
+                }
+                std::vector<uint32_t> packed(words * (out_dists ? 2u : 1u));
+                hipError_t e = hipMemcpyAsync(d_list, list.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(hvs_k_gather_rows, dim3(hvs_ceil_div((uint32_t)words, 256u)), dim3(256), 0, c->stream, d_list, (uint32_t)cnt,
+                                       c->d_out_ids, c->k, scratch);
+                    if (out_dists)
+                        hipLaunchKernelGGL(hvs_k_gather_rows, dim3(hvs_ceil_div((uint32_t)words, 256u)), dim3(256), 0, c->stream, d_list,
+                                           (uint32_t)cnt, reinterpret_cast<const uint32_t*>(c->d_out_dists), c->k, scratch + words);
+                    e = hipMemcpyAsync(packed.data(), scratch, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (d_list_tmp) (void)hipFree(d_list_tmp);
+                if (e != hipSuccess) return fail(c, HVS_EHIP, std::string("hvs_query: fetching the re-run rows: ") + hipGetErrorString(e));
+                for (size_t i = 0; i < cnt; ++i) {
+                    std::memcpy(out_ids + (size_t)list[i] * c->k, packed.data() + i * c->k, c->k * sizeof(uint32_t));
+                    if (out_dists) std::memcpy(out_dists + (size_t)list[i] * c->k, packed.data() + words + i * c->k, c->k * sizeof(float));
+                }
+            } else {
+                for (uint32_t qi : list) {
+                    HVS_HIP(c, hipMemcpyAsync(out_ids + (size_t)qi * c->k, c->d_out_ids + (size_t)qi * c->k, c->k * sizeof(uint32_t),
+                                              hipMemcpyDeviceToHost, c->stream));
+                    if (out_dists)
+                        HVS_HIP(c, hipMemcpyAsync(out_dists + (size_t)qi * c->k, c->d_out_dists + (size_t)qi * c->k,
+                                                  c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                }
+                HVS_HIP(c, hipStreamSynchronize(c->stream));
+            }
         }
-        HVS_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     return HVS_OK;

@@ -2590,6 +2590,16 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     }
 }
 
+// result rows of the queries in `list`, packed: dst[i][0..k) = src[list[i]][0..k)  (ids, or distances as bit patterns)
+__global__ void hvs_k_gather_rows(const uint32_t* __restrict__ list, uint32_t count, const uint32_t* __restrict__ src, uint32_t k,
+                                  uint32_t* __restrict__ dst)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count * k) return;
+    const uint32_t i = e / k, j = e - i * k;
+    dst[e] = src[(size_t)list[i] * k + j];
+}
+
 // planner probe: rows of D as type-0 queries (every `step`-th row from step / 2)
 __global__ void hvs_k_probe_queries(const float* __restrict__ D, uint32_t n, uint32_t step, uint32_t count, float* __restrict__ Q)
 {

@@ -93,8 +93,9 @@ struct HvsPairAsScalar {  // view the lane's 50 query pairs as 100 floats
 
 // SCALAR_ORDER = false: the hot path's SIMD summation order (optimized_impl.h:96-125);
 // SCALAR_ORDER = true : the baseline engine's sequential order (baseline.hpp:53-64), BASELINE.json configs[0].
+// (three workgroups per CU: at four the 128-register budget spilled 10-22 registers of the 100 query components)
 template <bool SCALAR_ORDER, int CAP>
-__global__ __launch_bounds__(256, 4) void hvs_k_scan_exact(
+__global__ __launch_bounds__(256, 3) void hvs_k_scan_exact(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
     unsigned long long* __restrict__ counters, uint32_t knn)
@@ -196,13 +197,81 @@ struct HvsLdsRow2 {
         return (i & 1) ? hvs_f2{v.z, v.w} : hvs_f2{v.x, v.y};
     }
 };
+// Exact-order distance of an LDS-staged row, software-pipelined by hand: the row's 25 ds_read_b128 are issued two b-steps
+// (4 reads, 16 components) ahead of the packed arithmetic that consumes them, alternating between two register sets, so
+// that every group of 8 independent v_pk_add / v_pk_mul / v_pk_add triples runs while the next group's reads are in
+// flight.  (Left to the compiler the loop kept 2 reads in flight and waited for each: ~35 s_nop and 27 s_waitcnt per row.)
+// The arithmetic and its order per accumulator are hvs_exact_dist_pk's: acc2[k] takes dims (8b + 2k, 8b + 2k + 1) for
+// b = 0..11 in order, then the masked tail, then the hsum tree (optimized_impl.h:96-125, :37-47).
+#define HVS_LDS_STEP(LO, HI, B)                                                                     \
+    {                                                                                               \
+        hvs_f2 t0 = hvs_f2{LO.x, LO.y} - q2[4 * (B) + 0], t1 = hvs_f2{LO.z, LO.w} - q2[4 * (B) + 1]; \
+        hvs_f2 t2 = hvs_f2{HI.x, HI.y} - q2[4 * (B) + 2], t3 = hvs_f2{HI.z, HI.w} - q2[4 * (B) + 3]; \
+        t0 = t0 * t0;                                                                               \
+        t1 = t1 * t1;                                                                               \
+        t2 = t2 * t2;                                                                               \
+        t3 = t3 * t3;                                                                               \
+        a0 = a0 + t0;                                                                               \
+        a1 = a1 + t1;                                                                               \
+        a2 = a2 + t2;                                                                               \
+        a3 = a3 + t3;                                                                               \
+    }
+// one group: two b-steps from registers (X0..X3), then the reads that refill them (float4 index NEXT.., or none)
+#define HVS_LDS_GROUP(X0, X1, X2, X3, B, NEXT)          \
+    HVS_LDS_STEP(X0, X1, (B))                           \
+    HVS_LDS_STEP(X2, X3, (B) + 1)                       \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    if ((NEXT) >= 0 && (NEXT) + 3 < 24) {               \
+        X0 = rowp[(NEXT) >= 0 ? (NEXT) : 0];            \
+        X1 = rowp[(NEXT) >= 0 ? (NEXT) + 1 : 0];        \
+        X2 = rowp[(NEXT) >= 0 ? (NEXT) + 2 : 0];        \
+        X3 = rowp[(NEXT) >= 0 ? (NEXT) + 3 : 0];        \
+    }                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ float hvs_exact_dist_pk_lds(const float4* rowp, const hvs_f2* q2)
+{
+    hvs_f2 a0 = hvs_f2{0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+    float4 A0 = rowp[0], A1 = rowp[1], A2 = rowp[2], A3 = rowp[3];
+    float4 B0 = rowp[4], B1 = rowp[5], B2 = rowp[6], B3 = rowp[7];
+    __builtin_amdgcn_sched_barrier(0);
+    HVS_LDS_GROUP(A0, A1, A2, A3, 0, 8)
+    HVS_LDS_GROUP(B0, B1, B2, B3, 2, 12)
+    HVS_LDS_GROUP(A0, A1, A2, A3, 4, 16)
+    HVS_LDS_GROUP(B0, B1, B2, B3, 6, 20)
+    float4 TL;
+    HVS_LDS_STEP(A0, A1, 8)
+    HVS_LDS_STEP(A2, A3, 9)
+    __builtin_amdgcn_sched_barrier(0);
+    TL = rowp[24];  // dims 96..99: the masked tail
+    __builtin_amdgcn_sched_barrier(0);
+    HVS_LDS_STEP(B0, B1, 10)
+    HVS_LDS_STEP(B2, B3, 11)
+    {
+        hvs_f2 t2 = hvs_f2{TL.x, TL.y} - q2[48];
+        hvs_f2 t3 = hvs_f2{TL.z, TL.w} - q2[49];
+        t2 = t2 * t2;
+        t3 = t3 * t3;
+        a2 = a2 + t2;
+        a3 = a3 + t3;
+    }
+    const hvs_f2 s01 = a0 + a2;  // (a0+a4, a1+a5)
+    const hvs_f2 s23 = a1 + a3;  // (a2+a6, a3+a7)
+    const float a = s01.x + s01.y;
+    const float b2 = s23.x + s23.y;
+    return a + b2;
+}
+#undef HVS_LDS_GROUP
+#undef HVS_LDS_STEP
+
 struct HvsLdsRow1 {
     const float* p;
     __device__ __forceinline__ float operator[](int i) const { return p[i]; }
 };
 
+// (two workgroups per CU: the 100 query components + two register sets of row data in flight (hvs_exact_dist_pk_lds) do not
+// fit the 168 registers of three)
 template <bool SCALAR_ORDER, int CAP>
-__global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
+__global__ __launch_bounds__(256, 2) void hvs_k_scan_exact_lds(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
     unsigned long long* __restrict__ counters, uint32_t knn)
@@ -292,8 +361,7 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact_lds(
                     dist = hvs_scalar_order_dist(d1, q1);
                 } else {
                     // packed f32 math: measured 14.0 k type-0 queries/s at D=1e7 against 12.5 k with the 300 unpacked ops
-                    HvsLdsRow2 dv{rowp};
-                    dist = hvs_exact_dist_pk(dv, q2);
+                    dist = hvs_exact_dist_pk_lds(rowp, q2);
                 }
                 if (pass && !(dist >= tau)) {
                     mylist[cnt] = hvs_make_key(dist, j0 + r);
