@@ -97,7 +97,8 @@ struct hvs_ctx {
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;      // queries for the exact engine; d_ovf_count[0..1] = exact, retry
     uint32_t* d_retry_list = nullptr;                            // queries whose guessed threshold was not verified
     uint32_t fallback_queries = 0, retry_queries = 0;
-    HvsGuessTable guess_tab[2]{};  // order statistics of the guessed thresholds for k = guess_k: [0] batches, [1] retry batches
+    HvsGuessTable guess_tab[13]{};  // order statistics of the guessed thresholds for k = guess_k: [0] proven (retry batches),
+    bool guess_have[13] = {};       // [p] failure target 10^-p
     uint32_t guess_k = 0;
 
     uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
@@ -168,7 +169,11 @@ const uint32_t kRadixMid = kGuess ? pow2_floor(env_u32("HVS_RADIX_MID", HVS_RADI
 // smallest order statistic a guessed threshold may use, and -log10 of the chance that one guess leaves fewer than k rows
 // below it (plan_guess)
 const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 3u, 1u, 256u);
-const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 3u, 1u, 12u);
+// HVS_GUESS_PFAIL unset (0): by batch size -- 10^-3 for batches of 2^18 queries and more, 10^-4 from 2^15, 10^-5 below: a
+// retry batch costs a fixed ~0.8 ms of latency-bound rounds whatever its size, which a batch of 10^4 queries (2.6 ms)
+// cannot afford every time while a batch of 2^21 (650 ms) gains 3 % from the tighter guesses
+const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 0u, 0u, 12u);
+uint32_t guess_pfail_for(uint32_t nqb) { return kGuessPfail ? kGuessPfail : (nqb >= (1u << 18) ? 3u : (nqb >= (1u << 15) ? 4u : 5u)); }
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
 
@@ -525,7 +530,7 @@ int build_tiles(hvs_ctx* c, int fmt)
 }
 
 int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list, bool proven_last);
-HvsGuessTable plan_guess(uint32_t k, bool proven);
+HvsGuessTable plan_guess(uint32_t k, bool proven, uint32_t pfail);
 
 // the tile format the context's engine setting asks for (HVS_FMT_NONE: HVS_ENGINE_AUTO found no filter worth running)
 int want_format(const hvs_ctx* c)
@@ -624,7 +629,7 @@ int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
     // what a filter without any error band would have handed over: m (radix - 1) rows per level under the guessed thresholds
     double ideal = 0.0;
     {
-        const HvsGuessTable G = plan_guess(c->k, false);
+        const HvsGuessTable G = plan_guess(c->k, false, guess_pfail_for(P));
         double seen = 1.0;  // fraction of the rows seen, from the last level backwards
         for (uint32_t j = c->lv.K; j >= 1u; --j) {
             seen /= (double)c->lv.radix[j];
@@ -970,10 +975,10 @@ uint32_t guess_m(double F, uint32_t k, double target)
 // `proven` (retry batches; HVS_GUESS=0): m = k at every level -- the proven threshold, which cannot fail (a query that
 // failed under a guess did so because the rows it had seen were unlucky, and a larger guess from the same rows shares
 // that luck)
-HvsGuessTable plan_guess(uint32_t k, bool proven)
+HvsGuessTable plan_guess(uint32_t k, bool proven, uint32_t pfail)
 {
     HvsGuessTable G{};
-    const double target = std::pow(10.0, -(double)kGuessPfail);
+    const double target = std::pow(10.0, -(double)pfail);
     for (int i = 0; i < HVS_GUESS_STEPS; ++i)
         G.m[i] = (uint16_t)((kGuess && !proven) ? guess_m(std::exp2(-(double)i / 8.0), k, target) : k);
     G.floor_m = (uint16_t)std::min(k, (kGuess && !proven) ? kGuessMid : k);
@@ -1000,12 +1005,16 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     const HvsLevels L = c->lv;
     HvsItems W{c->d_items, c->d_lvloff, c->d_cursor, HVS_SEG};
     const uint32_t n = c->n;
-    if (c->guess_k != c->k) {  // (two tables per k: 168 x ~100 negative-binomial sums, ~10 ms on the host)
-        c->guess_tab[0] = plan_guess(c->k, false);
-        c->guess_tab[1] = plan_guess(c->k, true);
+    if (c->guess_k != c->k) {  // (tables are made on first use: 168 x ~100 negative-binomial sums each, ~10 ms on the host)
+        for (bool& h : c->guess_have) h = false;
         c->guess_k = c->k;
     }
-    const HvsGuessTable G = c->guess_tab[proven_last ? 1 : 0];
+    const uint32_t gslot = proven_last ? 0u : guess_pfail_for(nqb);  // slot 0: the proven table
+    if (!c->guess_have[gslot]) {
+        c->guess_tab[gslot] = plan_guess(c->k, proven_last, gslot ? gslot : 3u);
+        c->guess_have[gslot] = true;
+    }
+    const HvsGuessTable G = c->guess_tab[gslot];
     B.fail_code = (kGuess && !proven_last) ? HVS_FAIL_RETRY : HVS_FAIL_EXACT;
     if (sn != n && !list)
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,

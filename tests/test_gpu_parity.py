@@ -522,6 +522,33 @@ def test_filter_engines_on_degenerate_value_ranges(fengine):
         T.check_parity(d, q, ids, ref, got_dists=dists)
 
 
+@pytest.mark.parametrize("force_type", [0, -1], ids=["config1_type0", "config2_mixed"])
+def test_baseline_configs_1_and_2_d1e6_q1e4(force_type):
+    """BASELINE configs[1] / [2] at their exact size: D = 10^6, Q = 10^4 in one call, type-0 only and mixed types.  Every
+    engine returns the exact engine's bits for all 10^4 queries; the oracle confirms a sample."""
+    n, nq = 1_000_000, 10_000
+    with PKG.Engine(0) as e:
+        e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
+        e.gen_queries(nq, T.SEED_QUERY, T.GEN_V1, 100, force_type, 0)
+        queries = e.download_queries(0, nq)
+        res = {}
+        for engine in [PKG.ENGINE_AUTO, PKG.ENGINE_EXACT_SCAN] + FILTER_ENGINES:
+            e.set_engine(engine)
+            e.query_resident(0, nq, 1.0)
+            e.sync()
+            t = e.last_timing()
+            assert t.nq == nq and (engine == PKG.ENGINE_AUTO or t.engine == engine)
+            res[engine] = e.download_results(0, nq)
+            print("engine", engine, "ran", t.engine, "device ms %.2f" % t.query_ms, "retried", t.retry_queries, "fallback", t.fallback_queries)
+        nodes = e.download_data(0, n)
+    want_i, want_d = res[PKG.ENGINE_EXACT_SCAN]
+    for engine, (ids, d) in res.items():
+        assert np.array_equal(ids, want_i) and np.array_equal(d.view(np.uint32), want_d.view(np.uint32)), engine
+    sel = np.arange(0, nq, nq // 64)[:64]
+    ref, _ = T.oracle_query(nodes, queries[sel], threads=8)
+    T.check_parity(nodes, queries[sel], want_i[sel], ref, got_dists=want_d[sel])
+
+
 def test_largest_batch_2pow21_queries_filters_agree():
     """The largest batch the library forms (2^21 queries, the bench default) at D = 10^7: the INT8 and BF16
     filters must return identical bits for every query, and the exact scan must confirm a 2048-query sample."""
