@@ -2430,8 +2430,8 @@ __device__ __forceinline__ uint32_t hvs_guess_m(const HvsLevels& L, const HvsGue
 // with m the smallest order statistic whose chance of leaving fewer than k rows of the WHOLE range below tau is under a
 // target (hvs.hip, plan_guess): if a fraction F of the query's rows has been seen, the number of rows of the whole
 // range below the m-th smallest seen distance is m + NegBin(m, F).  k = 100, target 10^-5: F = 1/4 (in front of the
-// last level of radix 4) -> m = 46, the level hands ~140 rows to the exact kernel instead of 300; F = 1/64 -> m = 11;
-// F = 1/1024 -> m = 5.  F is the query's own (hvs_guess_m: a narrow predicate range sees a different share of its rows
+// last level of radix 4) -> m = 45, the level hands ~135 rows to the exact kernel instead of 300; F = 1/64 -> m = 10;
+// F = 1/1024 -> m = 4 (10^-3, the target of large batches: 40 / 7 / 3).  F is the query's own (hvs_guess_m: a narrow predicate range sees a different share of its rows
 // than the level radices say).  Nothing is taken on trust:
 //   * tau only ever decreases, every row with exact distance <= tau of its level reaches the exact kernel (the filter's
 //     bound, see theta below) and the top-k truncation only drops keys above k kept ones -- so after the last level

@@ -112,6 +112,18 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
                 if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
                 if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);  // the wave in its epilogue goes first
                 bool anyhit = false;
+#ifdef LAB_FOLD
+                // thresholds folded into the accumulators (spare K slots): ONE max over the lane's 64 accumulators, one compare
+                int mall = acc[0][0][0];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int m = max(max(acc[0][q][0], acc[0][q][1]), acc[0][q][2]);
+                    m = max(max(m, acc[0][q][3]), acc[1][q][0]);
+                    m = max(max(m, acc[1][q][1]), acc[1][q][2]);
+                    mall = max(max(mall, m), acc[1][q][3]);
+                }
+                anyhit = mall >= theta[0];
+#else
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     int m = max(max(acc[0][q][0], acc[0][q][1]), acc[0][q][2]);
@@ -120,6 +132,7 @@ __global__ __launch_bounds__(256, OCC) void loop(const uint4* __restrict__ in, i
                     m = max(m, acc[1][q][3]);
                     anyhit = anyhit | (m >= theta[q]);
                 }
+#endif
                 if (__ballot(anyhit) != 0ull) {
                     hits++;
                     keep += acc[0][0][3];
@@ -411,6 +424,33 @@ int main(int argc, char** argv)
         int launches = 0;
         while (total < 4000.0) { total += run(f, 5) * 5; launches += 5; }
         std::printf("hold %s: %d launches, %.2f ms each\n", argv[2], launches, total / launches);
+        return 0;
+    }
+    if (argc > 1 && !std::strcmp(argv[1], "bits")) {
+        // part 4 (round 3): does the operands' bit width move the rate (DVFS: fewer toggling multiplier bits, higher clock)?
+        // every int8 operand byte is a random value shifted right arithmetically by `sh` bits (range +-127 >> sh); `zeros`:
+        // 28 of every 128 K positions are zero, as in the filter's K = 100 tiles
+        for (int zeros = 0; zeros < 2; ++zeros)
+            for (int sh = 0; sh <= 4; ++sh) {
+                unsigned long long s2 = 999;
+                std::vector<unsigned> hb(h.size());
+                for (size_t i = 0; i < hb.size(); ++i) {
+                    unsigned w = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        s2 = s2 * 6364136223846793005ull + 1442695040888963407ull;
+                        int v = (int)(signed char)(s2 >> 40) >> sh;
+                        // K position of this byte inside the 16-byte fragment row: lanes 48..63 of the second k-step hold k = 112..127
+                        if (zeros && ((i * 4 + b) % 64) >= 50) v = 0;  // ~22 % of the bytes
+                        w |= ((unsigned)v & 0xFFu) << (8 * b);
+                    }
+                    hb[i] = w;
+                }
+                hipMemcpy(g_in, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+                const float lo = run(l_loop<1, 2>, 3), br = run(l_brand<1, 2>, 3);
+                std::printf("operands +-%3d%s: filter-shaped loop 16x16x64 %.2f ms %.2f G pair-blocks/s | bare chains %.2f ms %.2f G\n", 127 >> sh,
+                            zeros ? ", 22 %% zero bytes" : "", lo, 2048.0 * 4 * g_tiles * 4 / (lo * 1e-3) / 1e9, br,
+                            2048.0 * 4 * g_iters * 2 / (br * 1e-3) / 1e9);
+            }
         return 0;
     }
     for (int rep = 0; rep < 2; ++rep) {
