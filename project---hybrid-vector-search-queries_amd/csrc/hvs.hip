@@ -1047,10 +1047,14 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     // few long-lived blocks per group (2: -4 % of the step at 262144 queries) and small batches enough blocks to
     // fill the chip
     const uint32_t rescore_blocks = kRescoreBlocks ? kRescoreBlocks : std::max(2u, std::min(8u, hvs_ceil_div(4096u, B.ngroups)));
-    // One filter -> re-score -> merge round per level.
-    for (uint32_t level = 1; level <= L.K; ++level) {
+    // One filter -> re-score -> merge round per level.  (Sharing a round between the two low levels of a small batch --
+    // BASELINE configs[1]/[2], 10^4 queries: m (R - 1) = 1000 rows per query to the exact kernel instead of 2 x 60 for one
+    // re-score + merge less -- was measured in round 3: 2.85 ms instead of 2.08 ms per 10^4 mixed queries.  Round 2 measured
+    // the same for doubling levels.)
+    for (uint32_t level = 1; level <= L.K;) {
+        const uint32_t last = level;
         HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
-        {
+        for (; level <= last; ++level) {
             const int ev = kernel_timer_begin(c);
             // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
             const dim3 fgrid(4u * (uint32_t)c->num_cus);
@@ -1075,7 +1079,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
         else
             hipLaunchKernelGGL(hvs_k_rescore<false>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
                                sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_counters);
-        launch_merge(level == L.K, level + 1u);
+        launch_merge(last == L.K, last + 1u);
     }
     // queries this batch could not answer go on the call's lists (retry with a proven threshold / exact engine); they
     // are answered again when the call's results are first needed (resolve_overflow) -- the batch never waits for the host

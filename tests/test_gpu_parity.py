@@ -226,11 +226,13 @@ def test_mfma_engine_overflow_falls_back_to_exact(fengine):
     assert st["identical"] == st["queries"]
 
 
-def test_mfma_accumulation_error_is_inside_the_budget(tmp_path):
-    """the filter's bound assumes |mfma chain - exact| <= 256 u sum|terms|; measure it."""
+@pytest.mark.parametrize("flag", ["-DCHECK_BF16", "-DCHECK_F16"], ids=["bf16", "f16"])
+def test_mfma_accumulation_error_is_inside_the_budget(tmp_path, flag):
+    """the filter's bound assumes |mfma chain - exact| <= 256 u sum|terms|; measure it for both 16-bit float
+    tile formats (FP16: half denormals may be flushed by the matrix pipe, which the bound allows for)."""
     import subprocess
     exe = str(tmp_path / "mfma_bound_check.out")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", flag,
                     os.path.join(T.REPO, "tests", "mfma_bound_check.hip"), "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     print(r.stdout)
