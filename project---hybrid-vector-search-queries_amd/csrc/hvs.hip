@@ -764,6 +764,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb, uint32_t want_fcap = HVS_F
     HvsBatch& B = c->fb;
     int rc;
     if (slots > c->fb_slots_cap) {
+        c->fb_slots_cap = 0;  // (a failed allocation below leaves no half-sized workspace behind)
 #define HVS_A(field, count) \
     if ((rc = dev_alloc(c, &B.field, (size_t)(count)))) return rc
         HVS_A(qid, slots);
@@ -794,10 +795,12 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb, uint32_t want_fcap = HVS_F
     // candidate lists and survivor-entry lists: sized in entries, shared out over the slots / groups of the batch
     const size_t need_cand = (size_t)slots * want_fcap, need_pairs = (size_t)groups * HVS_GROUP * want_fcap;
     if (need_cand > c->fb_cand_entries) {
+        c->fb_cand_entries = 0;  // (dev_alloc releases the old buffer first: nothing is held if it fails)
         if ((rc = dev_alloc(c, &B.cand, need_cand))) return rc;
         c->fb_cand_entries = need_cand;
     }
     if (need_pairs > c->fb_pair_entries) {
+        c->fb_pair_entries = 0;
         if ((rc = dev_alloc(c, &B.pairs, need_pairs))) return rc;
         c->fb_pair_entries = need_pairs;
     }

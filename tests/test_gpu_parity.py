@@ -785,6 +785,19 @@ def run(nodes, queries, tag, want_retry):
 nodes = T.gen_data(n, 71, T.GEN_V1, 10); queries = T.gen_queries(nq, 72, T.GEN_V1, 10)
 w = run(nodes, queries, 'uniform', os.environ.get('HVS_GUESS_PFAIL') == '1')
 ref, _ = T.oracle_query(nodes, queries[:96]); T.check_parity(nodes, queries[:96], w[:96], ref)
+# 1b. other k through the retry batches (their candidate capacity follows k (radix - 1))
+if os.environ.get('HVS_GUESS_PFAIL') == '1':
+    for k in (8, 200):
+        with PKG.Engine(0) as x:
+            x.set_engine(PKG.ENGINE_EXACT_SCAN); x.set_k(k); x.load_data(nodes)
+            wk = x.query(queries[:3000], 1.0, want_dists=False)
+        with PKG.Engine(0) as e:
+            e.set_engine(PKG.ENGINE_MFMA_I8); e.set_k(k); e.load_data(nodes)
+            gk = e.query(queries[:3000], 1.0, want_dists=False)
+            t = e.last_timing()
+            assert np.array_equal(gk, wk), k
+            assert t.retry_queries > 0, k
+            print('k', k, 'retried', t.retry_queries, 'exact fallback', t.fallback_queries)
 # 2. vectors drift with the timestamp: rows that are neighbours in the T ordering are neighbours in space
 drift = nodes.copy(); drift[:, 2:] += 40.0 * drift[:, 1:2] * np.sign(rng.standard_normal(100)).astype(np.float32)
 qd = queries.copy(); qd[:, 4:] += 40.0 * rng.random((nq, 1), dtype=np.float32) * np.sign(rng.standard_normal(100)).astype(np.float32)
