@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256, 3) void hvs_k_scan_exact(
 // ds_read_b128.  This removes the scalar-load round trips of hvs_k_scan_exact from the row loop
 // (two dependent s_load + s_waitcnt per row there); arithmetic and admission are identical.
 // ---------------------------------------------------------------------------------------------
-#define HVS_LDS_ROWS 32
+#ifndef HVS_LDS_ROWS
+#define HVS_LDS_ROWS 16   // rows per staged block (32: 8 more staging registers, which spill at three workgroups per CU)
+#endif
 #define HVS_LDS_ROW_F 104  // floats per staged row (416 B, 16-B aligned)
 
 struct HvsLdsRow2 {
@@ -228,9 +230,39 @@ struct HvsLdsRow2 {
         X3 = rowp[(NEXT) >= 0 ? (NEXT) + 3 : 0];        \
     }                                                   \
     __builtin_amdgcn_sched_barrier(0);
+#ifndef HVS_LDS_RING3
+#define HVS_LDS_RING3 1   // three single-step register sets (6 reads in flight, 24 registers); 0: two double-step sets (8 reads, 32
+                          // registers: needs two workgroups per CU -- measured 0.216 against 0.237 of the FP32 peak on type-0)
+#endif
 __device__ __forceinline__ float hvs_exact_dist_pk_lds(const float4* rowp, const hvs_f2* q2)
 {
     hvs_f2 a0 = hvs_f2{0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+#if HVS_LDS_RING3
+    float4 A0 = rowp[0], A1 = rowp[1], B0 = rowp[2], B1 = rowp[3], C0 = rowp[4], C1 = rowp[5];
+    __builtin_amdgcn_sched_barrier(0);
+#define HVS_LDS_ONE(X0, X1, B, NEXT)                    \
+    HVS_LDS_STEP(X0, X1, (B))                           \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    if ((NEXT) >= 0) {                                  \
+        X0 = rowp[(NEXT) >= 0 ? (NEXT) : 0];            \
+        if ((NEXT) + 1 < 25) X1 = rowp[(NEXT) >= 0 ? (NEXT) + 1 : 0]; \
+    }                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    HVS_LDS_ONE(A0, A1, 0, 6)
+    HVS_LDS_ONE(B0, B1, 1, 8)
+    HVS_LDS_ONE(C0, C1, 2, 10)
+    HVS_LDS_ONE(A0, A1, 3, 12)
+    HVS_LDS_ONE(B0, B1, 4, 14)
+    HVS_LDS_ONE(C0, C1, 5, 16)
+    HVS_LDS_ONE(A0, A1, 6, 18)
+    HVS_LDS_ONE(B0, B1, 7, 20)
+    HVS_LDS_ONE(C0, C1, 8, 22)
+    HVS_LDS_ONE(A0, A1, 9, 24)     // A0 <- dims 96..99 (the masked tail); A1 unused
+    HVS_LDS_ONE(B0, B1, 10, -1)
+    HVS_LDS_ONE(C0, C1, 11, -1)
+    const float4 TL = A0;
+#undef HVS_LDS_ONE
+#else
     float4 A0 = rowp[0], A1 = rowp[1], A2 = rowp[2], A3 = rowp[3];
     float4 B0 = rowp[4], B1 = rowp[5], B2 = rowp[6], B3 = rowp[7];
     __builtin_amdgcn_sched_barrier(0);
@@ -246,6 +278,7 @@ __device__ __forceinline__ float hvs_exact_dist_pk_lds(const float4* rowp, const
     __builtin_amdgcn_sched_barrier(0);
     HVS_LDS_STEP(B0, B1, 10)
     HVS_LDS_STEP(B2, B3, 11)
+#endif
     {
         hvs_f2 t2 = hvs_f2{TL.x, TL.y} - q2[48];
         hvs_f2 t3 = hvs_f2{TL.z, TL.w} - q2[49];
@@ -268,10 +301,13 @@ struct HvsLdsRow1 {
     __device__ __forceinline__ float operator[](int i) const { return p[i]; }
 };
 
-// (two workgroups per CU: the 100 query components + two register sets of row data in flight (hvs_exact_dist_pk_lds) do not
-// fit the 168 registers of three)
+// (three workgroups per CU = three waves per SIMD, 168 registers: the 100 query components, three register sets of row data
+// in flight (hvs_exact_dist_pk_lds) and the staging registers of a 16-row block fit without spilling)
+#ifndef HVS_LDS_SCAN_WGS
+#define HVS_LDS_SCAN_WGS 3
+#endif
 template <bool SCALAR_ORDER, int CAP>
-__global__ __launch_bounds__(256, 2) void hvs_k_scan_exact_lds(
+__global__ __launch_bounds__(256, HVS_LDS_SCAN_WGS) void hvs_k_scan_exact_lds(
     const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
     uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
     unsigned long long* __restrict__ counters, uint32_t knn)
