@@ -1,4 +1,4 @@
-"""Differential fuzzing on a GPU box: the MFMA engines (BF16 and INT8 filters) must return the exact engine's bits (ids AND
+"""Differential fuzzing on a GPU box: the filter engines (BF16, INT8, FP16 tiles) and HVS_ENGINE_AUTO must return the exact engine's bits (ids AND
 distances) for random data shapes, category counts, value ranges, special attribute values, query
 mixes and sample proportions.  Prints one line per case; exits 1 on the first mismatch."""
 import importlib, sys, time
@@ -9,9 +9,9 @@ PKG = importlib.import_module("project---hybrid-vector-search-queries_amd")
 
 def case(rng, i):
     n = int(rng.choice([100, 101, 1000, 4095, 4096, 5000, 33000, 70000, 200000, 1000003]))
-    nq = int(rng.choice([1, 31, 33, 128, 129, 1000, 5000, 5000, 20000, 66000]))   # (the large ones: several start-position bins per class)
+    nq = int(rng.choice([1, 31, 33, 128, 129, 1000, 5000, 5000, 20000, 66000, 140000]))   # (the large ones: several start-position bins per class; 140000: a ramped host schedule)
     ncat = int(rng.choice([1, 2, 7, 100, 5000]))
-    profile = int(rng.choice([0, 1, 1, 1]))
+    profile = int(rng.choice([0, 1, 1, 1, 2, 3, 4, 5]))   # (2-5: clustered / PCA-like / heavy-tailed / out-of-box queries)
     nodes = T.gen_data(n, int(rng.integers(1 << 30)), profile, ncat)
     queries = T.gen_queries(nq, int(rng.integers(1 << 30)), profile, ncat)
     scale = float(rng.choice([1.0, 1.0, 1e-3, 50.0]))
@@ -40,15 +40,15 @@ def case(rng, i):
     if k < 8: k = 100
     parts = int(rng.choice([1, 1, 1, 2, 3]))                         # multi-GPU context with virtual ranks on GPU 0
     res = []
-    for engine in (1, 2, 3):
+    for engine in (1, 2, 3, 4, 0):
         with (PKG.Engine(0) if parts == 1 else PKG.Engine(devices=[0] * parts)) as e:
             e.set_engine(engine); e.set_k(k); e.load_data(nodes)
             ids, d = e.query(queries, sp); t = e.last_timing()
-        res.append((ids, d, t.engine, t.fallback_queries))
+        res.append((ids, d, t.engine, t.fallback_queries, t.retry_queries))
     same = all(np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) for r in res[1:])
-    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} k={k} parts={parts} engines={res[0][2]},{res[1][2]},{res[2][2]} fallback={res[1][3]},{res[2][3]} -> {'ok' if same else 'MISMATCH'}", flush=True)
+    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} k={k} parts={parts} engines={','.join(str(r[2]) for r in res)} fallback={','.join(str(r[3]) for r in res[1:])} retried={','.join(str(r[4]) for r in res[1:])} -> {'ok' if same else 'MISMATCH'}", flush=True)
     if not same:
-        bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1) | (res[0][0] != res[2][0]).any(axis=1))[0]
+        bad = np.nonzero(np.logical_or.reduce([(res[0][0] != r[0]).any(axis=1) for r in res[1:]]))[0]
         print("  first bad queries:", bad[:10], queries[bad[:3], :4]); np.savez("gpurun_out/fuzz_fail.npz", nodes=nodes, queries=queries, sp=sp)
     if n <= 5000 and nq <= 129:   # small cases also against the oracle
         with T.oracle_k(k):
