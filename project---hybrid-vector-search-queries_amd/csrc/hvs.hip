@@ -96,6 +96,8 @@ struct hvs_ctx {
     int num_cus = 256;
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;      // queries for the exact engine; d_ovf_count[0..1] = exact, retry
     uint32_t* d_retry_list = nullptr;                            // queries whose guessed threshold was not verified
+    uint32_t* d_demote_list = nullptr;                           // a call's exact list, moved aside when the tile format changes under it
+    uint32_t demote_cap = 0, demoted_queries = 0;
     uint32_t fallback_queries = 0, retry_queries = 0;
     HvsGuessTable guess_tab[13]{};  // order statistics of the guessed thresholds for k = guess_k: [0] proven (retry batches),
     bool guess_have[13] = {};       // [p] failure target 10^-p
@@ -1117,6 +1119,35 @@ int resolve_overflow(hvs_ctx* c)
         HVS_HIP(c, hipStreamSynchronize(c->stream));
         novf = c->h_ovf[0];
     }
+    // Many queries without a usable INT8 bound in one call (the planner's probe uses rows of D as queries: real queries can
+    // lie far outside the data's box, where the clip term drowns the band): under HVS_ENGINE_AUTO the 16-bit float tiles
+    // are built now -- for this call's list and for the calls to come -- instead of sending them all to the exact engine
+    // at 1 % of a filter's rate.  The list moves aside (the filter batches append their own failures to the exact list).
+    c->demoted_queries = 0;
+    if (c->engine == HVS_ENGINE_AUTO && HVS_IS_I8(c->tile_fmt) && novf >= std::max(256u, c->timing.nq / 50u) &&
+        env_u32("HVS_DEMOTE", 1u, 0u, 1u)) {
+        if (c->demote_cap < c->res_cap) {
+            int rc = dev_alloc(c, &c->d_demote_list, (size_t)c->res_cap);
+            if (rc) return rc;
+            c->demote_cap = c->res_cap;
+        }
+        HVS_HIP(c, hipMemcpyAsync(c->d_demote_list, c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+        int rc = build_tiles_chain(c, c->f16_rejected ? HVS_FMT_BF16 : HVS_FMT_F16);
+        if (rc) return rc;
+        if (!c->have_index) return fail(c, HVS_ESTATE, "internal: no 16-bit float tiles after the INT8 tiles");
+        c->planned_fmt = c->tile_fmt;
+        for (uint32_t off = 0; off < novf; off += kBatchMfma) {
+            const uint32_t m = std::min(kBatchMfma, novf - off);
+            if ((rc = run_batch_mfma(c, 0, m, c->pend_sn, c->d_demote_list + off, true))) return rc;
+        }
+        c->demoted_queries = novf;
+        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        novf = c->h_ovf[0];
+        c->timing.flags |= HVS_TIMING_FORMAT_CHANGED;
+        c->timing.engine = c->tile_fmt == HVS_FMT_F16 ? HVS_ENGINE_MFMA_F16 : HVS_ENGINE_MFMA_FILTER;
+    }
     c->fallback_queries = novf;
     c->timing.fallback_queries = novf;
     c->timing.retry_queries = nretry;
@@ -1333,7 +1364,7 @@ void leaf_destroy(hvs_ctx* c)
         HvsBatch& B = c->fb;
         void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
                       B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
-                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count, c->d_retry_list,
+                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count, c->d_retry_list, c->d_demote_list,
                       c->d_qlo, c->d_qhi, c->d_segcnt, c->d_segoff, c->d_lvloff, c->d_cursor, c->d_items};
         for (void* p : fp)
             if (p) (void)hipFree(p);
@@ -1731,12 +1762,14 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
     // overflowed queries: re-run by the exact engine, their rows fetched again
     const bool had_ovf = c->ovf_pending;
     if ((rc = resolve_overflow(c))) return rc;
-    if (had_ovf && (c->fallback_queries || c->retry_queries)) {
-        const uint32_t novf = c->fallback_queries, nretry = c->retry_queries;
-        std::vector<uint32_t> list((size_t)novf + nretry);
+    if (had_ovf && (c->fallback_queries || c->retry_queries || c->demoted_queries)) {
+        const uint32_t novf = c->fallback_queries, nretry = c->retry_queries, ndem = c->demoted_queries;
+        std::vector<uint32_t> list((size_t)novf + nretry + ndem);
         if (novf) HVS_HIP(c, hipMemcpy(list.data(), c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (nretry)
             HVS_HIP(c, hipMemcpy(list.data() + novf, c->d_retry_list, (size_t)nretry * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (ndem)
+            HVS_HIP(c, hipMemcpy(list.data() + novf + nretry, c->d_demote_list, (size_t)ndem * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (sink) {
             for (uint32_t qi : list) {
                 const size_t dst = ((size_t)sink->row0 + qi) * c->k;

@@ -758,6 +758,40 @@ def test_nonuniform_vector_laws_parity(profile):
     T.check_parity(nodes, queries[sel], want_i[sel], ref, got_dists=want_d[sel])
 
 
+def test_auto_engine_changes_tile_format_when_queries_leave_the_box():
+    """HVS_ENGINE_AUTO picks INT8 tiles for evenly filled data (the planner's probe uses rows of D as queries).  A call whose
+    queries lie far outside the data's bounding box has no usable INT8 bound for them: instead of the exact engine at 1 % of
+    a filter's rate, the 16-bit float tiles are built in mid-call and answer them, and later calls use those tiles."""
+    n, nq = 200_000, 6000
+    nodes = T.gen_data(n, 81, T.GEN_V1, 10)
+    inside = T.gen_queries(nq, 82, T.GEN_V1, 10)
+    outside = inside.copy()
+    outside[:, 4:] *= np.float32(3.0)                       # every query far outside [-6, 6)^100
+    with PKG.Engine(0) as x:
+        x.set_engine(PKG.ENGINE_EXACT_SCAN)
+        x.load_data(nodes)
+        want_in = x.query(inside, 1.0)
+        want_out = x.query(outside, 1.0)
+    with PKG.Engine(0) as e:
+        e.load_data(nodes)                                  # AUTO
+        ids, d = e.query(inside, 1.0)
+        t = e.last_timing()
+        assert t.engine == PKG.ENGINE_MFMA_I8 and t.flags == 0 and t.fallback_queries == 0
+        assert np.array_equal(ids, want_in[0]) and np.array_equal(d.view(np.uint32), want_in[1].view(np.uint32))
+        ids, d = e.query(outside, 1.0)
+        t = e.last_timing()
+        print("first call outside the box: engine", t.engine, "flags", t.flags, "exact fallback", t.fallback_queries, "device ms %.1f" % t.query_ms)
+        assert t.flags & 2 and t.engine in (PKG.ENGINE_MFMA_F16, PKG.ENGINE_MFMA_FILTER) and t.fallback_queries < nq // 20
+        assert np.array_equal(ids, want_out[0]) and np.array_equal(d.view(np.uint32), want_out[1].view(np.uint32))
+        ids, d = e.query(outside, 1.0)
+        t2 = e.last_timing()
+        print("second call: engine", t2.engine, "flags", t2.flags, "exact fallback", t2.fallback_queries, "device ms %.1f" % t2.query_ms)
+        assert t2.flags == 0 and t2.engine == t.engine and t2.fallback_queries < nq // 20
+        assert np.array_equal(ids, want_out[0]) and np.array_equal(d.view(np.uint32), want_out[1].view(np.uint32))
+    ref, _ = T.oracle_query(nodes, outside[:64])
+    T.check_parity(nodes, outside[:64], want_out[0][:64], ref, got_dists=want_out[1][:64])
+
+
 _GUESS_CODE = r"""
 import importlib, os, sys, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
