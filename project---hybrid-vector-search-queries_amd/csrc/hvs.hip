@@ -1193,10 +1193,12 @@ void staging_copy(void* dst, const void* src, size_t bytes)
 std::vector<uint32_t> batch_schedule(uint32_t nq, uint32_t step, bool ramp_allowed)
 {
     std::vector<uint32_t> out;
-    // (calls of 2^17 .. 2^21 queries -- e.g. one GPU's share of BASELINE configs[3] on an 8-GPU node, 5 x 10^5 -- ramp too,
-    // with edges of an eighth of the call)
-    const uint32_t edge = std::min(kBatchMfma / 8u, std::max(16384u, hvs_ceil_div(nq / 8u, 512u) * 512u));
-    const bool ramp = ramp_allowed && edge >= 1024u && nq >= 131072u && nq >= 4u * edge;
+    // (calls below 2^20 queries -- e.g. one GPU's share of BASELINE configs[3] on an 8-GPU node, 5 x 10^5 -- stay ONE batch:
+    // with the staging copies cut over 4 threads the two exposed transfers cost ~9 ms, less than what two small edge
+    // batches lose in efficiency; measured in round 3, 5 x 10^5 queries host -> host: one batch 178.5 ms, ramped 185.1 ms,
+    // two / three equal batches 183.3 / 189.0 ms, resident 169 ms)
+    const uint32_t edge = kBatchMfma / 8u;
+    const bool ramp = ramp_allowed && edge >= 1024u && nq >= 4u * edge;
     if (!ramp) {
         for (uint32_t off = 0; off < nq; off += step) out.push_back(std::min(step, nq - off));
         return out;
