@@ -2142,16 +2142,49 @@ int hvs_load_data(hvs_ctx* c, const float* rows, uint32_t n)
     if (!c) return HVS_EINVAL;
     if (!rows) return fail(c, HVS_EINVAL, "hvs_load_data: rows is NULL");
     if (c->kids.empty()) return leaf_load_data(c, rows, n);
-    // one upload over PCIe; then, at the same time, the first GPU builds its index and every other GPU takes its copy of D
-    // from the first over xGMI (each pair has its own link) and builds its own
-    int rc = leaf_upload_data(c->kids[0], rows, n);
-    if (rc) return fail(c, rc, c->kids[0]->err);
-    return for_each_leaf(c, [&](uint32_t r) {
-        if (r == 0u) {
-            HVS_HIP(c->kids[0], hipSetDevice(c->kids[0]->device));
-            return finish_data(c->kids[0]);
+    // D reaches the GPUs in two parallel phases: every GPU uploads ITS slice of the rows over its own PCIe link, then takes
+    // the other slices from its peers over xGMI (each pair has its own link) -- an all-gather by peer copies -- and builds
+    // its index.  (Round 2 uploaded everything to GPU 0 and let 7 peers pull 4 GB each from it after its index build;
+    // HVS_LOAD_GATHER=0 keeps one upload + peer copies for A/B runs.)
+    const uint32_t N = (uint32_t)c->kids.size();
+    if (N == 1u || !env_u32("HVS_LOAD_GATHER", 1u, 0u, 1u)) {
+        int rc = leaf_upload_data(c->kids[0], rows, n);
+        if (rc) return fail(c, rc, c->kids[0]->err);
+        return for_each_leaf(c, [&](uint32_t r) {
+            if (r == 0u) {
+                HVS_HIP(c->kids[0], hipSetDevice(c->kids[0]->device));
+                return finish_data(c->kids[0]);
+            }
+            return leaf_load_data_from_peer(c->kids[r], c->kids[0]);
+        });
+    }
+    std::vector<uint32_t> r0(N + 1u, 0u);
+    for (uint32_t r = 0; r < N; ++r) shard_range(n, r, N, r0[r], r0[r + 1]);
+    int rc = for_each_leaf(c, [&](uint32_t r) -> int {  // phase 1: own slice, host -> device
+        hvs_ctx* k = c->kids[r];
+        int r2 = begin_data(k, n);
+        if (r2) return r2;
+        HVS_HIP(k, hipEventRecord(k->ev_q0, k->stream));
+        const size_t off = (size_t)r0[r] * HVS_DCOLS, cnt = (size_t)(r0[r + 1] - r0[r]) * HVS_DCOLS;
+        if ((r2 = upload_rows(k, k->d_data + off, rows + off, cnt))) return r2;
+        HVS_HIP(k, hipStreamSynchronize(k->stream));
+        return HVS_OK;
+    });
+    if (rc) return rc;
+    return for_each_leaf(c, [&](uint32_t r) -> int {  // phase 2: the other slices, device -> device; then the index
+        hvs_ctx* k = c->kids[r];
+        HVS_HIP(k, hipSetDevice(k->device));
+        for (uint32_t step = 1; step < N; ++step) {  // (rank r starts with its right neighbour: the pairs of a step are disjoint)
+            const uint32_t p = (r + step) % N;
+            const size_t off = (size_t)r0[p] * HVS_DCOLS, cnt = (size_t)(r0[p + 1] - r0[p]) * HVS_DCOLS;
+            if (cnt)
+                HVS_HIP(k, hipMemcpyPeerAsync(k->d_data + off, k->device, c->kids[p]->d_data + off, c->kids[p]->device, cnt * sizeof(float),
+                                              k->stream));
         }
-        return leaf_load_data_from_peer(c->kids[r], c->kids[0]);
+        HVS_HIP(k, hipEventRecord(k->ev_q1, k->stream));
+        HVS_HIP(k, hipStreamSynchronize(k->stream));
+        k->n = n;
+        return finish_data(k);
     });
 }
 
