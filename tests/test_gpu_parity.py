@@ -605,7 +605,9 @@ def test_multi_gpu_context_virtual_ranks(engine):
     n, nq = 120_000, 10_001                       # 10001 = 3334 + 3334 + 3333: uneven parts
     nodes = T.gen_data(n, 91, T.GEN_V1, 30)
     queries = T.gen_queries(nq, 92, T.GEN_V1, 30)
-    queries[17, 10] = np.inf                      # one overflow/fallback query in the first part
+    queries[17, 10] = np.inf                      # overflow/fallback queries in every part (the peer gather re-sends their rows)
+    queries[5000, 11] = np.inf
+    queries[9000, 12] = np.nan
     with PKG.Engine(0) as one:
         one.set_engine(engine)
         one.load_data(nodes)
