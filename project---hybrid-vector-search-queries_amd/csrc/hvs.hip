@@ -168,6 +168,24 @@ const bool kGuess = env_u32("HVS_GUESS", 1u, 0u, 1u) != 0u;
 uint32_t pow2_floor(uint32_t x) { uint32_t p = 2u; while (p * 2u <= x) p *= 2u; return p; }
 const uint32_t kRadixLast = kGuess ? pow2_floor(env_u32("HVS_RADIX_LAST", HVS_RADIX_LAST, 2u, 64u)) : 2u;
 const uint32_t kRadixMid = kGuess ? pow2_floor(env_u32("HVS_RADIX_MID", HVS_RADIX_MID, 2u, 64u)) : 2u;
+// HVS_RADICES="4,8,32": the radices of the last levels, last level first (A/B runs); HVS_RADIX_MID continues behind them
+struct RadixPlan {
+    uint32_t r[16] = {};
+    bool set = false;
+    RadixPlan()
+    {
+        const char* v = std::getenv("HVS_RADICES");
+        if (!v || !*v || !kGuess) return;
+        int k = 0;
+        while (*v && k < 14) {
+            const unsigned long x = std::strtoul(v, const_cast<char**>(&v), 10);
+            if (x >= 2 && x <= 64) r[k++] = pow2_floor((uint32_t)x);
+            while (*v == ',' || *v == ' ') ++v;
+        }
+        set = k > 0;
+    }
+};
+const RadixPlan kRadixPlan;
 // smallest order statistic a guessed threshold may use, and -log10 of the chance that one guess leaves fewer than k rows
 // below it (plan_guess)
 const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 3u, 1u, 256u);
@@ -679,7 +697,7 @@ int build_index(hvs_ctx* c)
 {
     free_index(c);
     const uint32_t n = c->n;
-    const HvsLevels L = hvs_make_levels(n, kRadixLast, kRadixMid);
+    const HvsLevels L = hvs_make_levels(n, kRadixLast, kRadixMid, kRadixPlan.set ? kRadixPlan.r : nullptr);
     if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
     // survivor entries carry the block position in 22 bits: above 2^27 rows per GPU the exact engine answers
     // (such a data set is sharded over GPUs anyway: 2^27 rows are 54.8 GB of rows + 35 GB of INT8 index)
@@ -1062,7 +1080,8 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
         for (; level <= last; ++level) {
             const int ev = kernel_timer_begin(c);
             // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
-            const dim3 fgrid(4u * (uint32_t)c->num_cus);
+            static const uint32_t kWgsPerCu = env_u32("HVS_FILTER_WGS_PER_CU", 4u, 1u, 16u);
+            const dim3 fgrid(kWgsPerCu * (uint32_t)c->num_cus);
             W.segsize = c->segs.seg[level];
             if (fmt == HVS_FMT_I8X16)
                 hipLaunchKernelGGL(hvs_k_filter_i8x16, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct, c->d_tiles_t,

@@ -209,14 +209,19 @@ __host__ __device__ static inline uint32_t hvs_storage_to_block(const HvsLevels&
 // level table of an ordering with n rows (host).  Radices (powers of two) from the last level backwards: r_last, then
 // r_mid, ..., each cut down so that level 0 keeps >= 16 blocks (512 rows): n = 10^7 -> level 0 of 19 blocks, then
 // radices 16, 16, 16, 4.  r_last = r_mid = 2 gives round 2's doubling levels (up to 14 of them).
-static inline HvsLevels hvs_make_levels(uint32_t n, uint32_t r_last = HVS_RADIX_LAST, uint32_t r_mid = HVS_RADIX_MID)
+// `plan` (optional, A/B runs): radices of the last levels, last level first, 0-terminated; r_mid continues behind it
+static inline HvsLevels hvs_make_levels(uint32_t n, uint32_t r_last = HVS_RADIX_LAST, uint32_t r_mid = HVS_RADIX_MID,
+                                        const uint32_t* plan = nullptr)
 {
     HvsLevels L{};
     L.nblk = (n + 31u) / 32u;
     uint32_t rad[16];
     uint32_t K = 0, S = 1;
+    bool in_plan = plan != nullptr;
     for (;;) {
         uint32_t r = K == 0 ? r_last : r_mid;
+        if (in_plan && plan[K] == 0u) in_plan = false;
+        if (in_plan) r = plan[K];
         while (r >= 2u && (uint64_t)L.nblk / ((uint64_t)S * r) < 16u) r >>= 1;
         if (r < 2u || K >= 14u) break;
         rad[K++] = r;
