@@ -1978,7 +1978,7 @@ int for_each_resident_part(hvs_ctx* root, uint32_t q0, uint32_t nq, Fn fn)
 
 extern "C" {
 
-const char* hvs_version(void) { return "hvs-mi355x 0.2 (gfx950)"; }
+const char* hvs_version(void) { return "hvs-mi355x 0.3 (gfx950)"; }
 
 const char* hvs_last_global_error(void) { return g_global_err.c_str(); }
 

@@ -768,6 +768,9 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
 #ifndef HVS_HIT_TREE
 #define HVS_HIT_TREE 1         // sub-block dispatch of a tile with hits through a tree of scalar ORs (0: linear; A/B: +1.2 % queries/s with the tree)
 #endif
+#ifndef HVS_ONE_TILE_BODY
+#define HVS_ONE_TILE_BODY 1   // hvs_k_filter_mfma: one copy of the tile body (0: an inner / edge pair; measured +0.6 % for one copy on FP16 tiles)
+#endif
 #ifndef HVS_ORDER_MORTON
 #define HVS_ORDER_MORTON 0   // 1: Z-order of (range start, range end) instead of start bins sorted by end (A/B builds; measured in
                              // round 3: type-2 batches 597 vs 592 ms, mixed 675 vs 673 ms, 5 x 10^5-query batches equal: not adopted)
@@ -1717,10 +1720,14 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
                 load_tile(i);
                 wcnt = __builtin_amdgcn_readfirstlane(wcnt);
                 const bool inner = bp * 32u >= ra_max && bp * 32u + 32u <= rb_min;
+#if HVS_ONE_TILE_BODY
+                tile_body(bp, inner);  // one copy of the tile body, the range tests behind a small branch (as hvs_k_filter_i8x16)
+#else
                 if (inner)
                     tile_body(bp, true);
                 else
                     tile_body(bp, false);
+#endif
             }
         }
         stage_barrier();
