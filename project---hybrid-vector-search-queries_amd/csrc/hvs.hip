@@ -1076,7 +1076,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     // the same for doubling levels.)
     for (uint32_t level = 1; level <= L.K;) {
         const uint32_t last = level;
-        HVS_HIP(c, hipMemsetAsync(B.paircnt, 0, (size_t)B.ngroups * sizeof(uint32_t), c->stream));
+        // (the groups' entry counters are zero here: hvs_k_prep_groups clears them for the first level, every merge for the next)
         for (; level <= last; ++level) {
             const int ev = kernel_timer_begin(c);
             // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)

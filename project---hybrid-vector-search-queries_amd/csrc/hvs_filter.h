@@ -2501,6 +2501,8 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     const uint32_t slot = blockIdx.x * 4u + w;
     const uint32_t knn = B.knn;
     if (slot >= B.nslots) return;
+    // the group's survivor-entry list starts empty at the next level (this level's re-scoring is complete: stream order)
+    if (!FINAL && lane == 0u && (slot % HVS_GROUP) == 0u) B.paircnt[slot / HVS_GROUP] = 0;
     const uint32_t qi = B.qid[slot];
     if (qi == 0xFFFFFFFFu) return;
     uint64_t* buf = sbuf[w];
