@@ -894,6 +894,17 @@ def test_config3_host_path_4e6_queries_one_call():
         assert np.array_equal(ids, res)
         sel = np.arange(0, nq, nq // 48)[:48]
         nodes = e.download_data(0, n)
+    # the same call through the multi-GPU context with 8 parts ("virtual ranks" on this GPU): the orchestration an 8-GPU node
+    # runs -- slice uploads + peer all-gather of D, 8 host pipelines of 5 x 10^5 queries each writing their slice of the result
+    with PKG.Engine(devices=[0] * 8) as m:
+        m.reserve(nq)
+        m.load_data(nodes)
+        ids8 = m.query(queries, 1.0, want_dists=False)
+        t8 = m.last_timing()
+        assert t8.n_gpus == 8 and t8.nq == nq and t8.fallback_queries == 0
+        bad = np.nonzero((ids8 != ids).any(axis=1))[0]
+        assert bad.size == 0, "8-part context: first wrong query %d of %d wrong" % (bad[0], bad.size)
+        print("8 virtual ranks on one GPU: host->host %.0f ms for %d queries" % (t8.host_ms, nq))
     ref, _ = T.oracle_query(nodes, queries[sel], threads=16)
     T.check_parity(nodes, queries[sel], ids[sel], ref)
 
