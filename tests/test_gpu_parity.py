@@ -132,6 +132,12 @@ def test_resident_api_and_argument_errors(eng):
     assert t.main_kernel_ms > 0 or eng.engine_id in FILTER_ENGINES
     passing = sum(int(T._passes(nodes, q).sum()) for q in queries[100:600])
     assert t.pairs == passing
+    # stream-ordered hand-off (hvs_stream_wait): work on another stream starts after the context's work; the NULL stream here
+    eng.query_resident(0, 700, 1.0)
+    eng.stream_wait(0)
+    eng.sync()
+    ids_all, _ = eng.download_results(0, 700)
+    assert np.array_equal(ids_all[100:600], ids)
     with pytest.raises(PKG.HvsError):
         eng.query_resident(600, 200, 1.0)      # range outside the resident set
     with pytest.raises(PKG.HvsError):
@@ -167,6 +173,15 @@ def test_cli_driver_matches_reference_files(tmp_path):
     assert np.array_equal(T.read_dist_file(o + ".dist").view(np.uint32), want.view(np.uint32))
     bad = subprocess.run([PKG.cli_path(), "a", "b", "c", "d"], capture_output=True, text=True)
     assert bad.returncode == 1 and "[source_path] [query_path] [output_path]" in bad.stdout
+    # another k through the driver (the reference's KNN_LIMIT is a compile-time constant, optimized_impl.h:26)
+    r = subprocess.run([PKG.cli_path(), d, q, o + "10"], capture_output=True, text=True, env=dict(os.environ, HVS_K="10"))
+    assert r.returncode == 0, r.stderr
+    ids10 = np.fromfile(o + "10", np.uint32).reshape(-1, 10)
+    with T.oracle_k(10):
+        ref10, _ = T.oracle_query(nodes, queries)
+        T.check_parity(nodes, queries, ids10, ref10)
+    d10 = np.fromfile(o + "10.dist", np.uint8)
+    assert d10.size == 4 + 4 * ids10.size and int(d10[:4].view(np.uint32)[0]) == queries.shape[0]
 
 
 @pytest.mark.parametrize("fengine", FILTER_ENGINES, ids=FILTER_IDS)
