@@ -43,7 +43,8 @@
 #define HVS_FCAP 1024         // per-query candidate keys per round (the least: HvsBatch::fcap; small batches get more)
 #define HVS_GCAP (HVS_GROUP * 1024) // per-group survivor entries per round (the least: HvsBatch::gcap)
 #ifndef HVS_SEG
-#define HVS_SEG 256           // row blocks per filter work item (128: -1 % mixed, -2.7 % type-0: twice the item prologues)
+#define HVS_SEG 512           // row blocks per filter work item (round 3: 256 -> 512 +0.5 % at 2^21 queries, equal at 5 x 10^5; 1024
+                              // equal / -1 %; round 2: 128 -1 % mixed, -2.7 % type-0 against 256: the item prologues)
 #endif
 #ifndef HVS_STAGE
 #define HVS_STAGE 4           // tiles per LDS stage (one workgroup barrier per stage), BF16 tiles (7 KiB)
