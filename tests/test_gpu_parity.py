@@ -962,6 +962,33 @@ def test_d1e8_config4_hbm_sizing():
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
 
 
+def test_more_than_2pow27_rows_says_so_and_answers_exactly():
+    """Survivor entries carry the block position in 22 bits: a data set of more than 2^27 rows per GPU gets no filter index and
+    HVS_ENGINE_AUTO answers with the exact engine -- hvs_timing.flags says so (HVS_TIMING_INDEX_TOO_LARGE).  54.8 GB of rows
+    generated on the device; the returned distances are recomputed on the host from the returned rows."""
+    n, nq = (1 << 27) + 4096, 64
+    with PKG.Engine(0) as e:
+        e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
+        e.gen_queries(nq, T.SEED_QUERY + 3, T.GEN_V1, 100, -1, 0)
+        queries = e.download_queries(0, nq)
+        e.query_resident(0, nq, 1.0)
+        e.sync()
+        t = e.last_timing()
+        ids, dists = e.download_results(0, nq)
+        assert t.engine == PKG.ENGINE_EXACT_SCAN and (t.flags & 1) == 1 and t.nq == nq
+        assert ids.max() < n and np.all(np.diff(dists, axis=1) >= 0)
+        for qi in (0, 17, 40, 63):
+            rows = np.stack([e.download_data(int(r), 1)[0] for r in ids[qi]])
+            want = T.oracle_dists_for_ids(rows, queries[qi:qi + 1], np.arange(100, dtype=np.uint32)[None, :])
+            assert np.array_equal(want.view(np.uint32), dists[qi:qi + 1].view(np.uint32))
+            typ = int(queries[qi, 0])
+            notpad = ids[qi] < n - 100
+            if typ & 1:
+                assert np.all((rows[:, 0] == queries[qi, 1])[notpad])
+            if typ & 2:
+                assert np.all(((rows[:, 1] >= queries[qi, 2]) & (rows[:, 1] <= queries[qi, 3]))[notpad])
+
+
 @pytest.mark.parametrize("engine", [PKG.ENGINE_EXACT_SCAN] + FILTER_ENGINES, ids=["exact"] + FILTER_IDS)
 @pytest.mark.parametrize("path", KGOLDENS, ids=[os.path.basename(p)[:-4] for p in KGOLDENS])
 def test_other_k_matches_reference_built_with_that_k(path, engine):
