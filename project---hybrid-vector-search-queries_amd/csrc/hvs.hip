@@ -699,8 +699,8 @@ int build_index(hvs_ctx* c)
     const uint32_t n = c->n;
     const HvsLevels L = hvs_make_levels(n, kRadixLast, kRadixMid, kRadixPlan.set ? kRadixPlan.r : nullptr);
     if (L.off[L.K + 1] != L.nblk) return fail(c, HVS_EINVAL, "internal: level table does not cover the blocks");
-    // survivor entries carry the block position in 22 bits: above 2^27 rows per GPU the exact engine answers
-    // (such a data set is sharded over GPUs anyway: 2^27 rows are 54.8 GB of rows + 35 GB of INT8 index)
+    // survivor entries carry the block position in 24 bits: above 2^29 rows per GPU the exact engine answers
+    // (2^29 rows are 219 GB of rows alone: such a data set is sharded over GPUs anyway)
     c->index_too_large = L.nblk > HVS_ENTRY_MAX_BLOCKS;
     if (c->index_too_large) return HVS_OK;
     c->lv = L;
@@ -781,6 +781,7 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb, uint32_t want_fcap = HVS_F
 {
     const uint32_t slots = hvs_ceil_div(nqb + 5u * 32u + (HVS_WG_WAVES + 1u) * HVS_GROUP, HVS_GROUP) * HVS_GROUP;
     const uint32_t groups = slots / HVS_GROUP;
+    if (slots > HVS_ENTRY_MAX_SLOTS) return fail(c, HVS_EINVAL, "internal: batch too large for the survivor entries' slot field");
     HvsBatch& B = c->fb;
     int rc;
     if (slots > c->fb_slots_cap) {

@@ -671,32 +671,33 @@ __device__ __forceinline__ void hvs_flag_fail(const uint32_t code, uint32_t* __r
 
 // Survivor entry of the filter (8 bytes in the group's pair list): the lanes of one (tile, query block) whose
 // accumulators reached the threshold.  bits 0..15 accumulator mask (bit r = row (r & 3) + 8 (r >> 2) + 4 half of
-// the block), 16..37 block position (22 bits: orderings of up to 2^27 rows), 38 row half, 39..63 slot.
-#define HVS_ENTRY_MAX_BLOCKS (1u << 22)
-#define HVS_ENTRY_MAX_SLOTS (1u << 25)
+// the block), 16..39 block position (24 bits: orderings of up to 2^29 rows -- more than one GPU's HBM holds; round 2's 22 bits
+// stopped at 2^27 rows), 40 row half, 41..63 slot (23 bits: a batch has at most 2^21 queries + padding).
+#define HVS_ENTRY_MAX_BLOCKS (1u << 24)
+#define HVS_ENTRY_MAX_SLOTS (1u << 23)
 __device__ __forceinline__ uint64_t hvs_entry_make(uint32_t slot, uint32_t bp, uint32_t half, uint32_t mask)
 {
     const uint32_t lo = (bp << 16) | mask;
-    const uint32_t hi = (slot << 7) | (half << 6) | (bp >> 16);
+    const uint32_t hi = (slot << 9) | (half << 8) | (bp >> 16);
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t hvs_entry_slot(uint64_t e) { return (uint32_t)(e >> 39); }
+__device__ __forceinline__ uint32_t hvs_entry_slot(uint64_t e) { return (uint32_t)(e >> 41); }
 __device__ __forceinline__ uint32_t hvs_entry_mask(uint64_t e) { return (uint32_t)e & 0xFFFFu; }
 // position of row bit r of the entry
 __device__ __forceinline__ uint32_t hvs_entry_pos(uint64_t e, uint32_t r)
 {
     const uint32_t bp = (uint32_t)(e >> 16) & (HVS_ENTRY_MAX_BLOCKS - 1u);
-    const uint32_t half = (uint32_t)(e >> 38) & 1u;
+    const uint32_t half = (uint32_t)(e >> 40) & 1u;
     return bp * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
 // HVS_FMT_I8X16 entries: the lane of a 16x16 accumulator block holds ONE query and 4 consecutive rows, two row blocks per
 // tile: bits 0..7 accumulator mask (bit b = 4 rb + i: row 16 rb + 4 quad + i of the block), 8..9 quad (lane >> 4),
-// 16..37 block position, 39..63 slot.
+// 16..39 block position, 41..63 slot.
 __device__ __forceinline__ uint64_t hvs_entry16_make(uint32_t slot, uint32_t bp, uint32_t quad, uint32_t mask8)
 {
     const uint32_t lo = (bp << 16) | (quad << 8) | mask8;
-    const uint32_t hi = (slot << 7) | (bp >> 16);
+    const uint32_t hi = (slot << 9) | (bp >> 16);
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t hvs_entry16_mask(uint64_t e) { return (uint32_t)e & 0xFFu; }

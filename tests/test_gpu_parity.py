@@ -962,11 +962,12 @@ def test_d1e8_config4_hbm_sizing():
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
 
 
-def test_more_than_2pow27_rows_says_so_and_answers_exactly():
-    """Survivor entries carry the block position in 22 bits: a data set of more than 2^27 rows per GPU gets no filter index and
-    HVS_ENGINE_AUTO answers with the exact engine -- hvs_timing.flags says so (HVS_TIMING_INDEX_TOO_LARGE).  54.8 GB of rows
-    generated on the device; the returned distances are recomputed on the host from the returned rows."""
-    n, nq = (1 << 27) + 4096, 64
+def test_more_than_2pow27_rows_run_through_the_filter():
+    """Survivor entries carry the block position in 24 bits (22 in round 2, which sent data sets of more than 2^27 rows per GPU to
+    the exact engine): 2^27 + 4096 rows generated on the device (54.8 GB of rows + 35 GB of INT8 index), HVS_ENGINE_AUTO answers
+    with the filter engine, bit-equal to the exact engine; the returned distances are recomputed on the host from the
+    returned rows."""
+    n, nq = (1 << 27) + 4096, 2048
     with PKG.Engine(0) as e:
         e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
         e.gen_queries(nq, T.SEED_QUERY + 3, T.GEN_V1, 100, -1, 0)
@@ -975,9 +976,15 @@ def test_more_than_2pow27_rows_says_so_and_answers_exactly():
         e.sync()
         t = e.last_timing()
         ids, dists = e.download_results(0, nq)
-        assert t.engine == PKG.ENGINE_EXACT_SCAN and (t.flags & 1) == 1 and t.nq == nq
+        assert t.engine in FILTER_ENGINES and t.flags == 0 and t.nq == nq and t.fallback_queries == 0
         assert ids.max() < n and np.all(np.diff(dists, axis=1) >= 0)
-        for qi in (0, 17, 40, 63):
+        e.set_engine(PKG.ENGINE_EXACT_SCAN)
+        e.query_resident(0, 64, 1.0)
+        e.sync()
+        assert e.last_timing().engine == PKG.ENGINE_EXACT_SCAN
+        xi, xd = e.download_results(0, 64)
+        assert np.array_equal(xi, ids[:64]) and np.array_equal(xd.view(np.uint32), dists[:64].view(np.uint32))
+        for qi in (0, 17, 40, 63, 2047):
             rows = np.stack([e.download_data(int(r), 1)[0] for r in ids[qi]])
             want = T.oracle_dists_for_ids(rows, queries[qi:qi + 1], np.arange(100, dtype=np.uint32)[None, :])
             assert np.array_equal(want.view(np.uint32), dists[qi:qi + 1].view(np.uint32))
