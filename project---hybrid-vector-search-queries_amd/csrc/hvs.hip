@@ -79,7 +79,6 @@ struct hvs_ctx {
     bool i8_usable = false;
     bool i8_rejected = false;  // the INT8 tiles were built and their bound was unusable: do not try again
     bool f16_rejected = false; // likewise the FP16 tiles (components beyond the half-precision range)
-    float probe_cost[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // planner probe: modelled cost per format (0: not probed), see probe_format
     double index_ms = 0.0;
     bool index_too_large = false;  // more than 2^27 rows: no filter index (hvs_timing.flags says so)
     // ... and per-batch state
@@ -645,7 +644,6 @@ int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
     if (rc) return rc;
     const double base = HVS_IS_I8(c->tile_fmt) ? 1.0 : env_u32("HVS_PLAN_BF16_COST", 194u, 100u, 1000u) / 100.0;
     *cost = base + 2650.0 / (double)c->n * ((double)h[2] / P) + 3.0 * fails[1] / P + 142.0 * fails[0] / P;
-    c->probe_cost[c->tile_fmt] = (float)*cost;
     // what a filter without any error band would have handed over: m (radix - 1) rows per level under the guessed thresholds
     double ideal = 0.0;
     {
@@ -669,7 +667,6 @@ int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
 int plan_by_probe(hvs_ctx* c)
 {
     if (!env_u32("HVS_PLAN_PROBE", 1u, 0u, 1u) || std::getenv("HVS_FILTER_FORMAT")) return HVS_OK;
-    for (float& p : c->probe_cost) p = 0.f;
     double cost = 0.0, infl = 0.0, failed = 0.0;
     int rc = probe_format(c, &cost, &infl, &failed);
     if (rc) return rc;
