@@ -188,6 +188,14 @@ int hvs_last_timing(hvs_ctx *ctx, hvs_timing *out);
  * or a negative HVS_E* code.  Single-GPU contexts only. */
 int hvs_last_reruns(hvs_ctx *ctx, int which, uint32_t *out_idx, uint32_t cap);
 
+/* Host-side planning rules, exposed for tests (pure arithmetic: no GPU, no context).
+ * hvs_plan_guess_m: the order statistic m of a guessed threshold (csrc/hvs_filter.h, "Guessed thresholds") for k neighbours when
+ * a fraction `seen_fraction` of the query's rows has been seen and one guess may fail with probability 10^-pfail.
+ * hvs_plan_batches: the batch sizes hvs_query (host_pipeline != 0) or hvs_query_resident cuts a call of nq queries into for
+ * the filter engines; writes up to cap sizes to out (may be NULL) and returns their number. */
+uint32_t hvs_plan_guess_m(uint32_t k, double seen_fraction, uint32_t pfail);
+uint32_t hvs_plan_batches(uint32_t nq, int host_pipeline, uint32_t *out, uint32_t cap);
+
 const char *hvs_version(void);
 
 #ifdef __cplusplus

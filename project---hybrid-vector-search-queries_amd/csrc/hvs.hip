@@ -1978,6 +1978,18 @@ extern "C" {
 
 const char* hvs_version(void) { return "hvs-mi355x 0.3 (gfx950)"; }
 
+uint32_t hvs_plan_guess_m(uint32_t k, double seen_fraction, uint32_t pfail)
+{
+    return guess_m(seen_fraction, k, std::pow(10.0, -(double)pfail));
+}
+
+uint32_t hvs_plan_batches(uint32_t nq, int host_pipeline, uint32_t* out, uint32_t cap)
+{
+    const std::vector<uint32_t> sched = batch_schedule(nq, kBatchMfma, host_pipeline != 0);
+    for (size_t i = 0; out && i < sched.size() && i < cap; ++i) out[i] = sched[i];
+    return (uint32_t)sched.size();
+}
+
 const char* hvs_last_global_error(void) { return g_global_err.c_str(); }
 
 int hvs_create(hvs_ctx** out, int device)

@@ -153,6 +153,8 @@ def library():
         "hvs_last_timing": (C.c_int, [vp, C.POINTER(Timing)]),
         "hvs_last_reruns": (C.c_int, [vp, C.c_int, _u32p, C.c_uint32]),
         "hvs_version": (C.c_char_p, []),
+        "hvs_plan_guess_m": (C.c_uint32, [C.c_uint32, C.c_double, C.c_uint32]),
+        "hvs_plan_batches": (C.c_uint32, [C.c_uint32, C.c_int, _u32p, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

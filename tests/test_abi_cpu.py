@@ -135,3 +135,41 @@ def test_compare_tool_matches_reference_cli_and_is_tie_aware(tmp_path):
     r = subprocess.run([PKG.compare_path(), "--strict", "--data", str(tmp_path / "d.bin"), "--queries", str(tmp_path / "q.bin"),
                         str(tmp_path / "can.bin"), str(tmp_path / "broken.bin")], capture_output=True, text=True)
     assert r.returncode == 1 and "1 VIOLATIONS" in r.stdout
+
+
+def test_host_planning_rules_guess_order_statistic_and_batch_schedule():
+    """Host logic of the filter engines that needs no GPU (include/hvs.h, hvs_plan_*): the order statistic behind a guessed
+    threshold (csrc/hvs_filter.h, "Guessed thresholds") against a simulation of its own failure model, and the batch schedule
+    of a call (hvs_query stages its input by exactly this schedule)."""
+    lib = PKG.library()
+    m = lambda k, f, p: int(lib.hvs_plan_guess_m(k, C.c_double(f), p))
+    assert m(100, 0.25, 3) == 40 and m(100, 0.25, 5) == 45 and m(100, 1 / 64, 3) == 7 and m(100, 1 / 1024, 3) == 3
+    assert m(100, 1.0, 3) == 100 and m(100, 0.0, 3) == 100 and m(8, 0.25, 3) <= 8 and m(256, 0.25, 5) <= 256
+    for k in (8, 100, 256):
+        ms = [m(k, f, 3) for f in (1e-4, 1e-3, 0.01, 0.1, 0.25, 0.5, 0.9, 1.0)]
+        assert ms == sorted(ms) and ms[-1] == k               # the more rows seen, the higher the order statistic
+        assert m(k, 0.25, 6) >= m(k, 0.25, 3) >= m(k, 0.25, 1) >= 1
+    # the failure model: X ~ NegBin(m, F) unseen rows below the m-th smallest seen distance; the guess fails iff X + m < k
+    rng = np.random.default_rng(3)
+    for f, p in ((0.25, 2), (0.25, 3), (1 / 16, 2), (0.5, 3)):
+        mm = m(100, f, p)
+        x = rng.negative_binomial(mm, f, 4_000_000)
+        rate = float(np.mean(x + mm < 100))
+        worse = float(np.mean(rng.negative_binomial(mm - 1, f, 4_000_000) + mm - 1 < 100))
+        assert rate <= 10.0 ** -p * 1.15 and worse > 10.0 ** -p * 0.85, (f, p, mm, rate, worse)   # the SMALLEST m that meets the target
+    out = (C.c_uint32 * 64)()
+    def sched(nq, host):
+        cnt = int(lib.hvs_plan_batches(nq, host, out, 64))
+        return [int(out[i]) for i in range(cnt)]
+    big = 1 << 21
+    assert sched(500_000, 1) == [500_000] and sched(500_000, 0) == [500_000]          # a rank's share of configs[3] on 8 GPUs
+    assert sched((1 << 20) - 1, 1) == [(1 << 20) - 1]
+    s4 = sched(4_000_000, 1)
+    assert s4[0] == s4[-1] == big // 8 and sum(s4) == 4_000_000 and len(s4) == 4 and max(s4) <= big
+    assert all(b % 512 == 0 for b in s4[:-2]) and abs(s4[1] - s4[2]) <= 1024
+    assert sched(4_000_000, 0) == [big, 4_000_000 - big]
+    assert sched(0, 1) == [] and sched(1, 1) == [1]
+    for nq in (1 << 20, (1 << 20) + 1, 3 * big + 17, 10_000_000):
+        for host in (0, 1):
+            sc = sched(nq, host)
+            assert sum(sc) == nq and all(0 < b <= big for b in sc), (nq, host, sc)
