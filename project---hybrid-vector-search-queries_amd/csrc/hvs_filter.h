@@ -770,6 +770,10 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
 #ifndef HVS_HIT_TREE
 #define HVS_HIT_TREE 1         // sub-block dispatch of a tile with hits through a tree of scalar ORs (0: linear; A/B: +1.2 % queries/s with the tree)
 #endif
+#ifndef HVS_FILTER_SETPRIO
+#define HVS_FILTER_SETPRIO 0  // hvs_k_filter_i8x16: s_setprio around the matrix block (A/B builds: 1 high while multiplying, 2 high in the
+                              // epilogue; measured again in round 3, with few survivors left: -0.4 % either way)
+#endif
 #ifndef HVS_ONE_TILE_BODY
 #define HVS_ONE_TILE_BODY 1   // hvs_k_filter_mfma: one copy of the tile body (0: an inner / edge pair; measured +0.6 % for one copy on FP16 tiles)
 #endif
@@ -2066,6 +2070,11 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     //     after >= 6 LDS reads and >= 28 vector instructions, far beyond the 4-pass result latency;
     //   * the fragment / init registers are overwritten only by LDS reads issued after the last matrix instruction.
     auto chains = [&]() {
+#if HVS_FILTER_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(3);  // A/B: the multiplying wave keeps the matrix pipe
+#elif HVS_FILTER_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(0);  // A/B: the wave in its epilogue goes first
+#endif
 #pragma unroll
         for (int j = 0; j < NSUB; ++j)
 #pragma unroll
@@ -2076,6 +2085,11 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
 #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2)
                 asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[r2][j]) : "v"(af[2 * r2 + 1]), "v"(bq[j][1]));
+#if HVS_FILTER_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif HVS_FILTER_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     auto imax = [](int a, int b) { return a > b ? a : b; };
