@@ -1,9 +1,9 @@
-// hvs_filter.h -- the MFMA filter engines: matrix-core bound filter (INT8 or BF16 tiles) + exact-order re-scoring.
+// hvs_filter.h -- the MFMA filter engines: matrix-core bound filter (INT8, FP16 or BF16 tiles) + exact-order re-scoring.
 //
 // Idea.  The reference evaluates 300 non-fusable f32 operations for every (query,row) pair that
-// passes the predicate (optimized_impl.h:96-125).  Only ~100 + O(100 log n) of those pairs can ever
-// enter a query's top-100.  This engine proves, with a cheap matrix-core product and a rigorous
-// error bound, that almost every pair CANNOT enter the top-100 and runs the exact-order kernel only
+// passes the predicate (optimized_impl.h:96-125).  Only a few hundred of those pairs can ever
+// enter a query's top-k.  This engine proves, with a cheap matrix-core product and a rigorous
+// error bound, that almost every pair CANNOT enter the top-k and runs the exact-order kernel only
 // on the few survivors.  Membership and order of the answer are always decided by exact-order f32
 // distances, never by the approximate value, so the output is bit-identical to the exact engine's.
 //
@@ -14,21 +14,22 @@
 //     type 1 = the C==v run, type 3 = the T-window inside that run, type 2 = a T-window of the
 //     T ordering.  Ranges come from integer binary searches on order-preserving keys.
 //   * each ordering is cut into blocks of 32 consecutive positions, stored as MFMA A-operand fragments in
-//     one of two formats.  BF16: K padded 100 -> 112; k = 100..102 hold -|d|^2/2 split into three BF16
-//     pieces so that one chain of 7 v_mfma_f32_32x32x16_bf16 yields  s = q.d - |d|^2/2.  INT8 ("INT8 filter"
-//     below): rows and queries centred and quantised with one scale, 4 v_mfma_i32_32x32x32_i8 started from
-//     the rows' integer norm terms, exact integer arithmetic; 3 KiB of fragments + 256 B of side data per block.
+//     one tile format.  16-bit floats (BF16 or IEEE half): K padded 100 -> 112; k = 100..102 hold -|d|^2/2 split into
+//     three pieces so that one chain of 7 v_mfma_f32_32x32x16_{bf16,f16} yields  s = q.d - |d|^2/2.  INT8 ("INT8 filter"
+//     below): rows and queries centred and quantised with one scale, v_mfma_i32_16x16x64_i8 (or 32x32x32) started from
+//     the rows' integer norm terms, exact integer arithmetic.
 //   * blocks are stored LEVEL-INTERLEAVED: level 0 = every S0-th block, level j = the multiples of
-//     stride[j] not in an earlier level (stride[j-1] = radix[j] * stride[j]; radix 2, so the levels
-//     hold ..., 1/8, 1/4 and 1/2 of the blocks).  Any position range meets every level in one contiguous
-//     storage run, and level j doubles the rows a query has seen.  A query's threshold tau therefore
-//     tightens geometrically and each round hands only ~100 (+ error band) candidates per query to the
-//     exact kernel, whatever the range.
+//     stride[j] not in an earlier level (stride[j-1] = radix[j] * stride[j]; radices 16, ..., 16, 4 by default).  Any
+//     position range meets every level in one contiguous storage run, and level j multiplies the rows a query has seen
+//     by its radix.  The threshold of a level is GUESSED from the rows seen so far (see hvs_k_merge) and the answer is
+//     verified at the end, so each round hands only a few hundred candidates per query to the exact kernel, whatever
+//     the range and the radix.
 //
 // Per batch of queries:  prep (ranges, B fragments, norms) -> level 0 by the exact kernel
 // -> merge -> for each further level { MFMA filter (writes 8-byte survivor entries) -> re-scoring kernel
-// (expands the entries, exact-order distances) -> merge (top-100, new tau and threshold) }
-// -> pad + sort + write.  A query whose candidate list overflows is re-run by the exact engine.
+// (expands the entries, exact-order distances) -> merge (top-k, next threshold) }
+// -> verify + pad + sort + write.  A query whose guess fails its check is run again with proven thresholds (retry
+// batch); a query without a usable bound, or whose lists overflow there, is re-run by the exact engine.
 #pragma once
 
 #include "hvs_device.h"
