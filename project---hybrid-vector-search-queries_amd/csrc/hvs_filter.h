@@ -775,8 +775,9 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
 #define HVS_FILTER_SETPRIO 0  // hvs_k_filter_i8x16: s_setprio around the matrix block (A/B builds: 1 high while multiplying, 2 high in the
                               // epilogue; measured again in round 3, with few survivors left: -0.4 % either way)
 #endif
-#ifndef HVS_ONE_TILE_BODY
-#define HVS_ONE_TILE_BODY 1   // hvs_k_filter_mfma: one copy of the tile body (0: an inner / edge pair; measured +0.6 % for one copy on FP16 tiles)
+#ifndef HVS_H16_PREFETCH
+#define HVS_H16_PREFETCH 0    // hvs_k_filter_mfma: 1 = the next tile's LDS reads issue under this tile's epilogue, as in hvs_k_filter_i8x16
+                              // (measured on FP16 / BF16 tiles: 3 % SLOWER than reading them in front of the tile's own matrix block)
 #endif
 #ifndef HVS_ORDER_MORTON
 #define HVS_ORDER_MORTON 0   // 1: Z-order of (range start, range end) instead of start bins sorted by end (A/B builds; measured in
@@ -1605,13 +1606,16 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // A fragments and accumulator start of tile i from its stage buffer.  Start: 0 (BF16: the norm term sits in
     // k = 100..102) or the rows' nh (INT8): accumulator r of a lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     // -> 4 broadcast b128 reads
-    auto load_tile = [&](uint32_t i) {
-        const uint32_t rel = i - I0, buf = (rel / STG) & 1u, tt = rel % STG;
+    // `slot` = the tile's place in the two stage buffers (buffer * STG + tile within the stage): the caller steps it by one
+    // per tile instead of deriving it from i (as hvs_k_filter_i8x16)
+    const uint4* stile_flat = &stile[0][0];
+    auto load_tile = [&](uint32_t slot) {
     #pragma unroll
-        for (int ks = 0; ks < KM; ++ks) af[ks] = F::frag(stile[buf][tt * TILE_U4 + ks * 64 + lane]);
+        for (int ks = 0; ks < KM; ++ks) af[ks] = F::frag(stile_flat[slot * TILE_U4 + ks * 64 + lane]);
         if constexpr (kI8) {
             // 4th k-step: lanes 0..31 hold k = 96..111 of their row (4 real dimensions from the side data, then
             // zeros), lanes 32..63 hold k = 112..127 (zeros)
+            const uint32_t buf = slot / STG, tt = slot % STG;
             const uint32_t* tailw = reinterpret_cast<const uint32_t*>(&snrm[buf][tt * HVS_I8_NRM_U4]);
             const int t4 = lane < 32u ? (int)tailw[lane & 31u] : 0;
             af[KM] = hvs_i32x4{t4, 0, 0, 0};
@@ -1626,8 +1630,9 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         } else {
             acc0 = typename F::acc_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         }
-        bp = __builtin_amdgcn_readfirstlane(bpos[i]);  // scalar load; computing it (runtime division by radix-1) measured 4 % slower
     };
+    // the tile's block position: a scalar load (computing it -- runtime division by radix-1 -- measured 4 % slower)
+    auto load_bp = [&](uint32_t i) { bp = __builtin_amdgcn_readfirstlane(bpos[i]); };
     // the chains of one pair, interleaved k-step by k-step
     auto chains = [&](int pair) {
     #pragma unroll
@@ -1650,7 +1655,6 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
             for (int r = 3; r < 15; r += 2) m = F::max2(F::max2(m, acc[qb][r]), acc[qb][r + 1]);
             m = F::max2(m, acc[qb][15]);
             hm[qb] = __ballot(m >= theta[qb]);
-            if (!inner) hm[qb] &= __ballot(bpx * 32u + 32u > ra[qb]) & __ballot(bpx * 32u < rb[qb]);  // (each compare IS a lane mask)
     #ifdef HVS_EXPERIMENT_NOHIT
             hm[qb] = __ballot(m == (typename F::thr_t)12345678);  // keeps the max chain alive, (almost) never true: ceiling experiment
     #endif
@@ -1672,7 +1676,6 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
         wcnt += (uint32_t)__popcll(nz);
         if (wcnt > 192u) flush();
     };
-    auto valid = [&](uint32_t i) { return active && i >= i0 && i < i1; };  // wave-uniform
 
     // the positions every lane's range covers: [ra_max, rb_min) (lanes that can never hit do not count)
     uint32_t ra_max = 0u, rb_min = 0xFFFFFFFFu;
@@ -1700,41 +1703,76 @@ __global__ __launch_bounds__(64 * HVS_WG_WAVES, HVS_FILTER_OCC) void hvs_k_filte
     // with the LDS-DMA prefetch of the next stage in flight exposes the DMA latency once per stage).  A wait
     // the compiler does understand, once, here, clears its scoreboard.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    auto tile_body = [&](uint32_t bpx, bool inner) {
+    // Tile t: [LDS reads of its fragments] [28 / 16 matrix instructions] [epilogues] [survivors, rarely].  Round 3 took over from
+    // hvs_k_filter_i8x16: the wave's tile range per stage computed once, the stage slot stepped instead of derived, the range
+    // tests of edge blocks behind one branch, the hit tests as a tree (+2.7 % on FP16 / BF16 tiles, +3.7 % on 32x32x32 INT8
+    // tiles); NOT its read order (HVS_H16_PREFETCH: the next tile's fragment reads under this tile's epilogue), which costs
+    // 3 % here -- 7 KiB of fragments per tile and wave instead of 4, and the compiler's staggered chains already start the first
+    // epilogue under the last matrix instructions.
+    auto tile_body = [&](uint32_t bpx, bool inner, uint32_t inext, uint32_t slot_next) {
         chains(0);
         chains(1);
+#if HVS_H16_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(slot_next);  // (always: a conditional load makes the compiler copy the fragment registers per tile)
+        load_bp(inext);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         epilogue(0, bpx, inner);
         epilogue(1, bpx, inner);
-        uint64_t any = 0;
+        if (!inner) {  // blocks at the edge of some lane's own range: one small branch for the 8 per-lane range compares
     #pragma unroll
-        for (int qb = 0; qb < HVS_QB; ++qb) any |= hm[qb];
-        if (any != 0ull) {
-    #pragma unroll
-            for (int qb = 0; qb < HVS_QB; ++qb)
-                if (hm[qb] != 0ull) survivors(qb, bpx, inner);
+            for (int qb = 0; qb < HVS_QB; ++qb) hm[qb] &= __ballot(bpx * 32u + 32u > ra[qb]) & __ballot(bpx * 32u < rb[qb]);  // (each compare IS a lane mask)
+        }
+        const uint64_t h01 = hm[0] | hm[1], h23 = hm[2] | hm[3];
+        static_assert(HVS_QB == 4, "the hit tests are written for 4 query blocks");
+        if ((h01 | h23) != 0ull) {
+            if (h01 != 0ull) {
+                if (hm[0] != 0ull) survivors(0, bpx, inner);
+                if (hm[1] != 0ull) survivors(1, bpx, inner);
+            }
+            if (h23 != 0ull) {
+                if (hm[2] != 0ull) survivors(2, bpx, inner);
+                if (hm[3] != 0ull) survivors(3, bpx, inner);
+            }
         }
     };
     for (uint32_t st = 0; st < nstage; ++st) {
 #ifndef HVS_EXPERIMENT_NODMA
         if (st + 1u < nstage) issue_stage((st & 1u) ^ 1u, I0 + (st + 1u) * STG);
 #endif
-#pragma unroll 1
-        for (uint32_t tt = 0; tt < STG; ++tt) {
-            const uint32_t i = I0 + st * STG + tt;
-            if (i >= I1) break;
-            if (valid(i)) {
-                ++nblocks;
-                load_tile(i);
-                wcnt = __builtin_amdgcn_readfirstlane(wcnt);
-                const bool inner = bp * 32u >= ra_max && bp * 32u + 32u <= rb_min;
-#if HVS_ONE_TILE_BODY
-                tile_body(bp, inner);  // one copy of the tile body, the range tests behind a small branch (as hvs_k_filter_i8x16)
-#else
-                if (inner)
-                    tile_body(bp, true);
-                else
-                    tile_body(bp, false);
+        // this wave's tiles of the stage: [t0, t1)
+        const uint32_t s0 = I0 + st * STG;
+        const uint32_t t0 = i0 > s0 ? i0 : s0;
+        const uint32_t t1 = i1 < s0 + STG ? i1 : s0 + STG;  // (i1 <= I1)
+        if (active && t0 < t1) {
+            uint32_t slot = (st & 1u) * STG + (t0 - s0);
+#if HVS_H16_PREFETCH
+            load_tile(slot);
+            load_bp(t0);
 #endif
+#pragma unroll 1
+            for (uint32_t i = t0; i < t1; ++i) {
+                ++nblocks;
+#if !HVS_H16_PREFETCH
+                // fragments and block position in front of the tile's own matrix block.  (Measured on FP16 tiles, against
+                // this order: the reads under the previous tile's epilogue -3 %; only the block position's scalar load
+                // under it -1 %, and -2.5 % more with a scheduling barrier between the matrix block and the epilogue -- the
+                // compiler starts the first chain's epilogue between the last matrix instructions of the other three.)
+                load_tile(slot);
+                load_bp(i);
+#endif
+                wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+                const uint32_t bpx = bp;
+                const bool inner = bpx * 32u >= ra_max && bpx * 32u + 32u <= rb_min;
+                const bool more = i + 1u < t1;  // (last tile of the stage: re-read this one, unused)
+#if HVS_H16_PREFETCH
+                slot += more ? 1u : 0u;
+#else
+                slot += 1u;
+#endif
+                asm volatile("" : "+s"(slot));  // (otherwise the compiler re-derives it from i)
+                tile_body(bpx, inner, more ? i + 1u : i, slot);
             }
         }
         stage_barrier();
