@@ -51,6 +51,7 @@ cd $ROOT
 if [[ " $PARTS " == *" lab "* ]]; then
 ./scripts/shape_lab.out > $OUT/mfma_shape_lab.txt 2>&1 || true
 ./scripts/shape_lab.out bits > $OUT/operand_bits_lab.txt 2>&1 || true
+./scripts/h16_lab.out > $OUT/h16_shape_lab.txt 2>&1 || true   # hipcc --offload-arch=gfx950 -O3 scripts/h16_shape_lab.hip -o scripts/h16_lab.out
 ./scripts/shape_lab_fold.out bits > $OUT/operand_bits_lab_folded_thresholds.txt 2>&1 || true
 echo "lab done"
 fi
