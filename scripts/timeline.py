@@ -6,7 +6,9 @@ n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(tr)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-rows = rows[-n_last:]
+# the run ends with the download of the first timed batch (a tail of copy kernels): the last step ends at the last hvs kernel
+last = max(i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(('hvs_k', 'void hvs_k')))
+rows = rows[max(0, last + 1 - n_last):last + 1]
 t0 = int(rows[0]['Start_Timestamp'])
 prev_end = t0
 for r in rows:
