@@ -156,6 +156,8 @@ const uint32_t kBatch = env_u32("HVS_EXACT_BATCH", 65536u, 64u, 1u << 20);
 const uint32_t kBatchMfma = env_u32("HVS_MFMA_BATCH", 1u << 21, 128u, 1u << 21);  // (2^21: +2.2 % queries/s over 2^20, 34 GB of batch state)
 // re-scoring blocks per group (each stages the group's 128 queries in LDS): HVS_RESCORE_BLOCKS overrides
 const uint32_t kRescoreBlocks = env_u32("HVS_RESCORE_BLOCKS", 0u, 0u, 64u);  // 0: chosen per batch
+// small batches: level 0 (the exact seed kernel) is cut into chunks until about this many waves are in flight
+const uint32_t kSeedWaves = env_u32("HVS_SEED_WAVES", 16384u, 64u, 1u << 20);
 // exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
 const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
 // INT8 tiles are built for v_mfma_i32_16x16x64_i8 (HVS_FMT_I8X16: 1.16x the pair rate of the 32x32x32 shape in the
@@ -1045,7 +1047,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     const uint32_t l0blocks = L.off[1] - L.off[0];
     const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
     uint32_t seed_chunks = 1u;
-    if (l0blocks <= B.fcap / 32u && seed_waves < 16384u) seed_chunks = std::min(l0blocks, hvs_ceil_div(16384u, seed_waves));
+    if (l0blocks <= B.fcap / 32u && seed_waves < kSeedWaves) seed_chunks = std::min(l0blocks, hvs_ceil_div(kSeedWaves, seed_waves));
     with_cap(c->cap, [&](auto CAPT) {
         hipLaunchKernelGGL((hvs_k_seed_exact<decltype(CAPT)::value>), dim3((B.nslots + 255u) / 256u, std::max(1u, seed_chunks)), dim3(256), 0,
                            c->stream, c->d_data, n, sn, c->d_q, B, c->d_perm_ct, c->d_perm_t, c->d_bpos_ct, c->d_bpos_t, L, c->d_counters,

@@ -1071,6 +1071,17 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
 // The per-lane predicate is the slot's own position range.  Survivors go to cand[slot].
 // One wave per 64 slots.
 // ---------------------------------------------------------------------------------------------
+#ifndef HVS_SEED_LDS
+#define HVS_SEED_LDS 1      // level-0 rows through a wave-private LDS image (0: one by one through the scalar cache; A/B builds)
+#endif
+#ifndef HVS_SEED_STAGE
+#define HVS_SEED_STAGE 16u  // rows per image (a power of two dividing 32)
+#endif
+#ifndef HVS_SEED_UNROLL
+#define HVS_SEED_UNROLL 7   // gather loads of a lane in flight at a time (13 = all of a 16-row image: 50 registers spilled)
+#endif
+#define HVS_PRAGMA_(x) _Pragma(#x)
+#define HVS_PRAGMA(x) HVS_PRAGMA_(x)
 struct HvsUniformRowF2 {
     const hvs_f2* __restrict__ p;
     __device__ __forceinline__ hvs_f2 operator[](int i) const { return p[i]; }
@@ -1085,6 +1096,9 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
                                                            const uint32_t* __restrict__ bpos_t, HvsLevels L,
                                                            unsigned long long* __restrict__ counters, uint32_t nchunks)
 {
+#if HVS_SEED_LDS
+    __shared__ float4 srow[4][HVS_SEED_STAGE][26];  // per wave: 16 data rows as 16-byte aligned images x0..x99 (+ pad)
+#endif
     // nchunks > 1 (small batches, level 0 of at most 1024 rows): grid.y waves share one 64-slot group, each
     // takes every nchunks-th level-0 block and appends to the slots' lists with atomics -- a single wave per
     // group walks ~1000 randomly placed rows one after the other and is latency-bound (2 ms at 10^4 queries)
@@ -1117,24 +1131,65 @@ __global__ __launch_bounds__(256, 3) void hvs_k_seed_exact(const float* __restri
     uint32_t cnt = 0, nscan = 0;
     for (uint32_t i = lo + blockIdx.y; i < hi; i += nchunks) {
         const uint32_t b = bpos[i];
+        uint32_t kk = 0, kend = 0;  // chunked form: this lane's places [kk, kend) in its slot's list for the block's rows
+        if (nchunks > 1u) {         // wave-uniform
+            // ONE atomic per lane and block instead of one per row and lane: the rows of the block a lane takes are its
+            // range cut to the block, less those outside the sampled prefix
+            const uint32_t p0 = b * 32u, p1 = (p0 + 32u < n) ? p0 + 32u : n;
+            const uint32_t a = ra > p0 ? ra : p0, e = rb < p1 ? rb : p1;
+            uint32_t mine = a < e ? e - a : 0u;
+            if (sn < n) {
+                for (uint32_t pos = p0; pos < p1; ++pos)
+                    if (perm[pos] >= sn && pos >= ra && pos < rb) --mine;  // perm[pos]: wave-uniform (scalar) load
+            }
+            if (mine != 0u) {
+                kk = atomicAdd(&B.candcnt[slot], mine);
+                kend = kk + mine;
+                if (kend > B.fcap) {
+                    hvs_flag_fail(B.fail_code, B.overflow, slot);
+                    kend = kk < B.fcap ? B.fcap : kk;
+                }
+            }
+        }
         for (uint32_t r = 0; r < 32u; ++r) {
             const uint32_t pos = b * 32u + r;
             if (pos >= n) break;
+#if HVS_SEED_LDS
+            // The block's rows sit anywhere in D (perm): fetched one by one through the scalar cache, every row is a dependent
+            // round trip to HBM (0.23 ms for 960 rows x 10^4 queries, a quarter of the exact engine's rate).  16 rows at a
+            // time are gathered by the whole wave instead (800 8-byte loads in flight) into a wave-private LDS image and
+            // read back as broadcast ds_read_b128 by the exact engine's row loop (hvs_exact_dist_pk_lds).
+            if ((r & (HVS_SEED_STAGE - 1u)) == 0u) {
+                const uint32_t p0 = pos, p1 = p0 + HVS_SEED_STAGE;
+                if (__ballot(ra < p1 && rb > p0) == 0ull) {  // no lane's range meets these rows
+                    r += HVS_SEED_STAGE - 1u;
+                    continue;
+                }
+                hvs_f2* img = reinterpret_cast<hvs_f2*>(&srow[threadIdx.x >> 6][0][0]);
+HVS_PRAGMA(unroll HVS_SEED_UNROLL)
+                for (uint32_t t = 0; t < (HVS_SEED_STAGE * 50u + 63u) / 64u; ++t) {
+                    const uint32_t e = lane + 64u * t, rr = e / 50u, c = e % 50u;
+                    if (e < HVS_SEED_STAGE * 50u && p0 + rr < n) {
+                        const uint32_t idr = perm[p0 + rr];
+                        img[rr * 52u + c] = *reinterpret_cast<const hvs_f2*>(D + (size_t)idr * HVS_DCOLS + 2u + 2u * c);
+                    }
+                }
+            }
+#endif
             const bool pass = pos >= ra && pos < rb;
             if (__ballot(pass) == 0ull) continue;
             const uint32_t id = perm[pos];
             if (id >= sn) continue;  // sampled prefix: rows [0, sn) of the original order only
             nscan += 64u;
+#if HVS_SEED_LDS
+            const float dist = hvs_exact_dist_pk_lds(&srow[threadIdx.x >> 6][r & (HVS_SEED_STAGE - 1u)][0], q2);
+#else
             HvsUniformRowF2 dv{reinterpret_cast<const hvs_f2*>(D + (size_t)id * HVS_DCOLS + 2)};
             const float dist = hvs_exact_dist_pk(dv, q2);
+#endif
             if (nchunks > 1u) {  // wave-uniform
-                if (pass) {
-                    const uint32_t k = atomicAdd(&B.candcnt[slot], 1u);
-                    if (k < B.fcap)
-                        mylist[k] = hvs_make_key(dist, id);
-                    else
-                        hvs_flag_fail(B.fail_code, B.overflow, slot);
-                }
+                if (pass && kk < kend) mylist[kk] = hvs_make_key(dist, id);
+                kk += pass ? 1u : 0u;
                 continue;
             }
             if (pass && dist <= tau) {
