@@ -33,6 +33,7 @@
 #pragma once
 
 #include "hvs_device.h"
+#include "hvs_kernels.h"  // hvs_exact_dist_pk_lds: the exact engine's row loop, run by hvs_k_seed_exact on its LDS images
 
 #define HVS_KPAD 112          // padded contraction length (7 MFMA k-steps of 16)
 #define HVS_KSTEPS 7
