@@ -1175,6 +1175,11 @@ HVS_PRAGMA(unroll HVS_SEED_UNROLL)
                         img[rr * 52u + c] = *reinterpret_cast<const hvs_f2*>(D + (size_t)idr * HVS_DCOLS + 2u + 2u * c);
                     }
                 }
+                // the image is written and read by different lanes of ONE wave: LDS operations of a wave execute in order,
+                // the fence keeps the compiler from moving the row loop's reads in front of the writes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 #endif
             const bool pass = pos >= ra && pos < rb;
