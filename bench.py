@@ -35,6 +35,64 @@ INT8_PEAK_TOPS = 5000.0    # dense INT8 MFMA peak (2x BF16 per clock)
 HBM_PEAK_GBS = 8000.0
 
 
+def configs12_leg(pkg, T, np, steps=20, warmup=3):
+    """BASELINE configs[1] / [2]: D = 10^6, Q = 10^4 (type-0 only / mixed types) on one GPU, each call ONE batch.
+    Per config: resident ms per call (inputs in HBM, results left in HBM: hvs_query_resident + hvs_sync), host -> host ms per
+    call (hvs_query on pageable buffers, warm context: the reference's timing scope, src/test.cpp:82-88), the step-level
+    fraction of the filter's MFMA peak (200 op x passing pairs / resident time), and hvs_load_data's time for the 408 MB set."""
+    n, nq, K = 1_000_000, 10_000, 100
+    out = {"n": n, "nq": nq, "steps": steps, "note": "each call is one batch of 10^4 queries; ms are means over `steps` calls after warm-up"}
+    with pkg.Engine(0) as e:
+        e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
+        nodes = e.download_data(0, n)
+    with pkg.Engine(0) as e:
+        t1 = time.perf_counter()
+        e.load_data(nodes)
+        out["load_data_ms"] = (time.perf_counter() - t1) * 1e3
+        t1 = time.perf_counter()
+        e.load_data(nodes)
+        out["load_data_ms_second_call"] = (time.perf_counter() - t1) * 1e3
+        del nodes
+        for name, ftype in (("config1_type0", 0), ("config2_mixed", -1)):
+            e.gen_queries(nq * (steps + warmup), T.SEED_QUERY, T.GEN_V1, 100, ftype, 0)
+            res_ms, dev_ms, kern_ms, pairs, retried, fallback = [], 0.0, 0.0, 0, 0, 0
+            for b in range(steps + warmup):
+                t1 = time.perf_counter()
+                e.query_resident(b * nq, nq, 1.0)
+                e.sync()
+                dt = time.perf_counter() - t1
+                if b >= warmup:
+                    tm = e.last_timing()
+                    res_ms.append(dt * 1e3)
+                    dev_ms += tm.query_ms
+                    kern_ms += tm.main_kernel_ms
+                    pairs += tm.pairs
+                    retried += tm.retry_queries
+                    fallback += tm.fallback_queries
+            engine_id = int(e.last_timing().engine)
+            peak = {2: BF16_PEAK_TFLOPS, 3: INT8_PEAK_TOPS, 4: BF16_PEAK_TFLOPS}.get(engine_id, FP32_PEAK_TFLOPS)
+            ids_res = e.download_results((steps + warmup - 1) * nq, nq, want_dists=False)
+            q_all = e.download_queries(0, nq * (steps + warmup))
+            ids_host = np.empty((nq, K), np.uint32)
+            host_ms = []
+            for b in range(steps + warmup):
+                q = q_all[b * nq:(b + 1) * nq]
+                t1 = time.perf_counter()
+                e.query(q, 1.0, want_dists=False, out_ids=ids_host)
+                dt = time.perf_counter() - t1
+                if b >= warmup:
+                    host_ms.append(dt * 1e3)
+            assert np.array_equal(ids_host, ids_res), "configs12: host path and resident path disagree"
+            r = float(np.mean(res_ms))
+            out[name] = {"resident_ms": r, "resident_ms_min": float(np.min(res_ms)), "device_ms": dev_ms / steps,
+                         "host_to_host_ms": float(np.mean(host_ms)), "host_to_host_ms_min": float(np.min(host_ms)),
+                         "queries_per_s_resident": nq / r * 1e3, "queries_per_s_host_to_host": nq / float(np.mean(host_ms)) * 1e3,
+                         "step_frac_of_mfma_peak": 200.0 * pairs / steps / (r / 1e3) / 1e12 / peak,
+                         "filter_kernel_frac": (200.0 * pairs / (kern_ms / 1e3) / 1e12 / peak) if kern_ms > 0 else None,
+                         "engine": engine_id, "retry_queries_per_call": retried / steps, "fallback_queries": fallback}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +112,8 @@ def main():
     ap.add_argument("--no-fixed-q", action="store_true",
                     help="skip the fixed-Q leg (rank 0's share of the 4x10^6-query set at 1, 2, 4, 8 GPUs, run on this GPU)")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--no-configs12", action="store_true", help="skip the BASELINE configs[1]/[2] leg (D = 10^6, Q = 10^4 on one GPU)")
+    ap.add_argument("--only-configs12", action="store_true", help="run only that leg and print its object")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the result gather even with one rank (rehearsal)")
     a = ap.parse_args()
@@ -83,6 +143,9 @@ def main():
     pkg = importlib.import_module("project---hybrid-vector-search-queries_amd")  # after torch: one HIP runtime
     import hvs_testlib as T
 
+    if a.only_configs12:
+        print(json.dumps({"configs12": configs12_leg(pkg, T, np)}))
+        return
     K = 100
     total_batches = a.warmup + a.steps
     eng = pkg.Engine(local_rank)
@@ -309,9 +372,11 @@ def main():
         out["parity"] = st
     elif rank == 0:
         out["cpu_baseline"] = None
+    eng.close()
+    if rank == 0 and world == 1 and not a.no_configs12:
+        out["configs12"] = configs12_leg(pkg, T, np)
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -44,7 +44,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define HVS_HD __host__ __device__ static inline
 #else
 #define HVS_HD static inline

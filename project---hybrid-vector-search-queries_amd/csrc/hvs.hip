@@ -56,6 +56,7 @@ struct hvs_ctx {
     // workspace of one query batch
     uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
     uint32_t *d_qidx = nullptr, *d_qorder = nullptr;
+    uint32_t *d_qra = nullptr, *d_qrb = nullptr;  // position range of each query of the batch, by batch-local index
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t batch_cap = 0;
@@ -125,6 +126,7 @@ struct hvs_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;
     static constexpr uint32_t kStageQ = 65536;  // queries per staging slot
     static constexpr int kRing = 4;
+    uint32_t in_cap_q[kRing] = {0, 0, 0, 0}, out_cap_q[kRing] = {0, 0, 0, 0}, outd_cap_q[kRing] = {0, 0, 0, 0};  // slot sizes in queries
     float* h_in[kRing] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* h_out_ids[kRing] = {nullptr, nullptr, nullptr, nullptr};
     float* h_out_dists[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -178,10 +180,21 @@ struct RadixPlan {
         const char* v = std::getenv("HVS_RADICES");
         if (!v || !*v || !kGuess) return;
         int k = 0;
+        bool ok = true;
         while (*v && k < 14) {
-            const unsigned long x = std::strtoul(v, const_cast<char**>(&v), 10);
+            char* end = nullptr;
+            const unsigned long x = std::strtoul(v, &end, 10);
+            if (end == v) {  // not a number ("4;8", "4x"): the whole variable is ignored
+                ok = false;
+                break;
+            }
+            v = end;
             if (x >= 2 && x <= 64) r[k++] = pow2_floor((uint32_t)x);
             while (*v == ',' || *v == ' ') ++v;
+        }
+        if (!ok) {
+            for (uint32_t& x : r) x = 0u;
+            k = 0;
         }
         set = k > 0;
     }
@@ -194,9 +207,32 @@ const uint32_t kGuessMid = env_u32("HVS_GUESS_MID", 3u, 1u, 256u);
 // retry batch costs a fixed ~0.8 ms of latency-bound rounds whatever its size, which a batch of 10^4 queries (2.6 ms)
 // cannot afford every time while a batch of 2^21 (650 ms) gains 3 % from the tighter guesses
 const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 0u, 0u, 12u);
-uint32_t guess_pfail_for(uint32_t nqb) { return kGuessPfail ? kGuessPfail : (nqb >= (1u << 18) ? 3u : (nqb >= (1u << 15) ? 4u : 5u)); }
+// (round 4: 10^-6 below 2^15 queries -- measured on BASELINE configs[1]/[2], 10^4 queries per batch: a failed guess costs the call a
+// host synchronisation and a retry batch of ~0.55 ms whose kernels are launch-bound; 10^-5 retried 0.3-0.45 queries per call,
+// 10^-6 none in 20 calls for 11 % more candidates: 2.21 / 1.80 ms per call against 2.27 / 1.90, profiles/r04/configs12_sweeps.txt)
+uint32_t guess_pfail_for(uint32_t nqb) { return kGuessPfail ? kGuessPfail : (nqb >= (1u << 18) ? 3u : (nqb >= (1u << 15) ? 4u : 6u)); }
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
+
+// HVS_TRACE=1: hvs_query prints the host-side phases of a call (microseconds since its start) to stderr -- where a small
+// call's wall time goes between the caller's buffers and the first / last kernel
+const bool kTrace = env_u32("HVS_TRACE", 0u, 0u, 1u) != 0u;
+struct HostTrace {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string line;
+    void mark(const char* what)
+    {
+        if (!kTrace) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), " %s@%.0f", what, us);
+        line += buf;
+    }
+    void flush(const char* tag, uint32_t nq)
+    {
+        if (kTrace) std::fprintf(stderr, "[hvs trace] %s nq=%u:%s\n", tag, nq, line.c_str());
+    }
+};
 
 int fail(hvs_ctx* c, int code, const std::string& msg)
 {
@@ -323,6 +359,8 @@ int ensure_batch_workspace(hvs_ctx* c, uint32_t nqb, const Plan& p)
         if ((rc = dev_alloc(c, &c->d_keys_sorted, (size_t)nqb))) return rc;
         if ((rc = dev_alloc(c, &c->d_qidx, (size_t)nqb))) return rc;
         if ((rc = dev_alloc(c, &c->d_qorder, (size_t)nqb))) return rc;
+        if ((rc = dev_alloc(c, &c->d_qra, (size_t)nqb))) return rc;
+        if ((rc = dev_alloc(c, &c->d_qrb, (size_t)nqb))) return rc;
         size_t tmp = 0;
         HVS_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                              (size_t)nqb, 0, 64, c->stream));
@@ -860,17 +898,16 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt,
         for (int k = 0; k < 5; ++k) c->class_counts[k] = counts[k];
     }
     hipLaunchKernelGGL(hvs_k_query_keys2, dim3((nqb + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, q0, nqb, list, c->d_keys_ct,
-                       c->d_keys_t, n, c->d_layout + 8, c->d_keys, c->d_qidx);
+                       c->d_keys_t, n, c->d_layout + 8, c->d_keys, c->d_qidx, c->d_qra, c->d_qrb);
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                          (size_t)nqb, 0, 64, c->stream));
-    hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, B.qid,
-                       B.rank, c->d_layout);
+    hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, q0, list,
+                       c->d_qra, c->d_qrb, B.qid, B.rank, B.ra, B.rb, c->d_layout);
     // (last argument: the batch is for a filter engine -- `host_counts` is the exact engine's range scan, which answers every
     // query itself, non-finite ones included)
-    hipLaunchKernelGGL(hvs_k_prep_slots, dim3((B.nslots + 255u) / 256u), dim3(256), 0, c->stream, c->d_q, B, c->d_keys_ct,
-                       c->d_keys_t, n, count_pairs ? 1 : 0, c->d_counters, fmt, c->d_quant, c->d_bounds, host_counts ? 0 : 1);
-    hipLaunchKernelGGL(hvs_k_prep_groups, dim3(B.ngroups), dim3(HVS_GROUP), 0, c->stream, c->d_q, B, fmt, c->d_quant);
+    hipLaunchKernelGGL(hvs_k_prep, dim3(B.ngroups), dim3(4 * HVS_GROUP), 0, c->stream, c->d_q, B, count_pairs ? 1 : 0, c->d_counters,
+                       fmt, c->d_quant, c->d_bounds, host_counts ? 0 : 1);
     HVS_HIP(c, hipGetLastError());
     return HVS_OK;
 }
@@ -943,7 +980,8 @@ int build_items(hvs_ctx* c)
     const HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
     const uint32_t nquads = hvs_ceil_div(B.ngroups, HVS_WG_WAVES);
-    const HvsSegs S = hvs_make_segs(L, nquads, 2u * (uint32_t)c->num_cus);
+    static const uint32_t kItemsPerSlot = env_u32("HVS_SEG_ITEMS", 8u, 1u, 64u);  // work items per resident workgroup a level should make
+    const HvsSegs S = hvs_make_segs(L, nquads, 2u * (uint32_t)c->num_cus, kItemsPerSlot);
     c->segs = S;
     const uint32_t nseg = S.first[L.K + 1];
     if (nquads > (1u << HVS_ITEM_QUAD_BITS)) return fail(c, HVS_EINVAL, "internal: too many query quads for the item code");
@@ -1009,18 +1047,31 @@ HvsGuessTable plan_guess(uint32_t k, bool proven, uint32_t pfail)
     return G;
 }
 
+// candidate keys per slot and round of a batch that runs every level with the PROVEN threshold (retry batches): up to
+// k (radix - 1) candidates per query and level, twice that for the band
+uint32_t proven_fcap(const hvs_ctx* c)
+{
+    uint32_t rmax = 2u;
+    for (uint32_t j = 1; j <= c->lv.K; ++j) rmax = std::max(rmax, c->lv.radix[j]);
+    return std::max<uint32_t>(HVS_FCAP, hvs_ceil_div(2u * c->k * (rmax - 1u), 256u) * 256u);
+}
+// queries per retry batch: as many as the candidate workspace the call's own batches already allocated can serve with
+// proven_fcap keys per slot -- re-running a long list must not ask for 3x the workspace of the batches it came from
+uint32_t proven_batch_step(const hvs_ctx* c)
+{
+    const size_t fit = c->fb_cand_entries / proven_fcap(c);
+    const size_t pad = 5u * 32u + (HVS_WG_WAVES + 1u) * HVS_GROUP + HVS_GROUP;  // (slot padding of ensure_filter_workspace)
+    uint32_t step = fit > pad + 4096u ? (uint32_t)std::min<size_t>(fit - pad, kBatchMfma) : 4096u;
+    step = std::max(512u, step / 512u * 512u);
+    return std::min(step, kBatchMfma);
+}
+
 // One batch through the filter engine: the resident range [q0, q0 + nqb), or the nqb query indices in the device array
 // `list` (retry batches: `proven_last`, failures go to the exact engine).
 int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uint32_t* list, bool proven_last)
 {
     const int fmt = c->tile_fmt;
-    // a retry batch runs every level with the proven threshold: up to k (radix - 1) candidates per query and level
-    uint32_t want_fcap = HVS_FCAP;
-    if (proven_last) {
-        uint32_t rmax = 2u;
-        for (uint32_t j = 1; j <= c->lv.K; ++j) rmax = std::max(rmax, c->lv.radix[j]);
-        want_fcap = std::max<uint32_t>(HVS_FCAP, hvs_ceil_div(2u * c->k * (rmax - 1u), 256u) * 256u);
-    }
+    const uint32_t want_fcap = proven_last ? proven_fcap(c) : HVS_FCAP;
     int rc = prep_batch(c, q0, nqb, sn == c->n && !list, fmt, false, list, want_fcap);
     if (rc) return rc;
     if ((rc = build_items(c))) return rc;
@@ -1076,7 +1127,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
     // the same for doubling levels.)
     for (uint32_t level = 1; level <= L.K;) {
         const uint32_t last = level;
-        // (the groups' entry counters are zero here: hvs_k_prep_groups clears them for the first level, every merge for the next)
+        // (the groups' entry counters are zero here: hvs_k_prep clears them for the first level, every merge for the next)
         for (; level <= last; ++level) {
             const int ev = kernel_timer_begin(c);
             // a fixed crew of workgroups pulls the level's work items (two resident per CU + spares)
@@ -1124,14 +1175,33 @@ int resolve_overflow(hvs_ctx* c)
     HVS_HIP(c, hipSetDevice(c->device));
     HVS_HIP(c, hipStreamSynchronize(c->stream));
     c->ovf_pending = false;
+    c->demoted_queries = 0;
     uint32_t novf = c->h_ovf[0];
     const uint32_t nretry = c->h_ovf[1];
     if (novf == 0u && nretry == 0u) return HVS_OK;
+    // what is left of a list when a re-run batch cannot get its workspace: appended to the exact engine's list, which needs none
+    auto rest_to_exact = [&](const uint32_t* list, uint32_t count) -> int {
+        (void)hipGetLastError();
+        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        const uint32_t have = c->h_ovf[0];
+        HVS_HIP(c, hipMemcpyAsync(c->d_ovf_list + have, list, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        const uint32_t total = have + count;
+        HVS_HIP(c, hipMemcpyAsync(c->d_ovf_count, &total, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        c->err.clear();
+        return HVS_OK;
+    };
     if (nretry) {
         c->retry_queries = nretry;
-        for (uint32_t off = 0; off < nretry; off += kBatchMfma) {
-            const uint32_t m = std::min(kBatchMfma, nretry - off);
+        const uint32_t step = proven_batch_step(c);
+        for (uint32_t off = 0; off < nretry; off += step) {
+            const uint32_t m = std::min(step, nretry - off);
             int rc = run_batch_mfma(c, 0, m, c->pend_sn, c->d_retry_list + off, true);
+            if (rc == HVS_ENOMEM) {
+                if ((rc = rest_to_exact(c->d_retry_list + off, nretry - off))) return rc;
+                break;
+            }
             if (rc) return rc;
         }
         HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1150,22 +1220,46 @@ int resolve_overflow(hvs_ctx* c)
             if (rc) return rc;
             c->demote_cap = c->res_cap;
         }
-        HVS_HIP(c, hipMemcpyAsync(c->d_demote_list, c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-        HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+        // The 16-bit float tiles first: when HBM has no room for them next to D (they are 1.7x the INT8 tiles) the INT8
+        // tiles come back and the exact engine answers the list as it always did -- slower, never an error.
+        const int had = c->tile_fmt;
         int rc = build_tiles_chain(c, c->f16_rejected ? HVS_FMT_BF16 : HVS_FMT_F16);
-        if (rc) return rc;
-        if (!c->have_index) return fail(c, HVS_ESTATE, "internal: no 16-bit float tiles after the INT8 tiles");
-        c->planned_fmt = c->tile_fmt;
-        for (uint32_t off = 0; off < novf; off += kBatchMfma) {
-            const uint32_t m = std::min(kBatchMfma, novf - off);
-            if ((rc = run_batch_mfma(c, 0, m, c->pend_sn, c->d_demote_list + off, true))) return rc;
+        if (rc == HVS_ENOMEM || (!rc && !c->have_index)) {
+            (void)hipGetLastError();
+            c->err.clear();
+            rc = build_tiles_chain(c, had);
+            if (rc == HVS_ENOMEM) {
+                (void)hipGetLastError();
+                c->err.clear();
+                rc = HVS_OK;
+            }
+            if (rc) return rc;
+            if (!c->have_index) c->have_index = true;  // (orderings only: the exact engine's range scans)
+        } else if (rc) {
+            return rc;
+        } else {
+            HVS_HIP(c, hipMemcpyAsync(c->d_demote_list, c->d_ovf_list, (size_t)novf * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, sizeof(uint32_t), c->stream));
+            c->planned_fmt = c->tile_fmt;
+            const uint32_t step = proven_batch_step(c);
+            uint32_t done = novf;
+            for (uint32_t off = 0; off < novf; off += step) {
+                const uint32_t m = std::min(step, novf - off);
+                rc = run_batch_mfma(c, 0, m, c->pend_sn, c->d_demote_list + off, true);
+                if (rc == HVS_ENOMEM) {
+                    if ((rc = rest_to_exact(c->d_demote_list + off, novf - off))) return rc;
+                    done = off;
+                    break;
+                }
+                if (rc) return rc;
+            }
+            c->demoted_queries = done;
+            HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HVS_HIP(c, hipStreamSynchronize(c->stream));
+            novf = c->h_ovf[0];
+            c->timing.flags |= HVS_TIMING_FORMAT_CHANGED;
+            c->timing.engine = c->tile_fmt == HVS_FMT_F16 ? HVS_ENGINE_MFMA_F16 : HVS_ENGINE_MFMA_FILTER;
         }
-        c->demoted_queries = novf;
-        HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HVS_HIP(c, hipStreamSynchronize(c->stream));
-        novf = c->h_ovf[0];
-        c->timing.flags |= HVS_TIMING_FORMAT_CHANGED;
-        c->timing.engine = c->tile_fmt == HVS_FMT_F16 ? HVS_ENGINE_MFMA_F16 : HVS_ENGINE_MFMA_FILTER;
     }
     c->fallback_queries = novf;
     c->timing.fallback_queries = novf;
@@ -1274,6 +1368,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     c->untimed_launches = 0;
     c->fallback_queries = 0;
     c->retry_queries = 0;
+    c->demoted_queries = 0;  // (a list of an earlier call must never be scattered into this call's results)
     HVS_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HVS_HIP(c, hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->stream));
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
@@ -1377,7 +1472,8 @@ void leaf_destroy(hvs_ctx* c)
     if (c->s_in) (void)hipStreamSynchronize(c->s_in);
     if (c->s_out) (void)hipStreamSynchronize(c->s_out);
     void* ptrs[] = {c->d_data, c->d_q,      c->d_out_ids,  c->d_out_dists, c->d_keys,     c->d_keys_sorted,
-                    c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters};
+                    c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters,
+                    c->d_qra,  c->d_qrb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     free_index(c);
@@ -1408,6 +1504,8 @@ void leaf_destroy(hvs_ctx* c)
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
 }
 
+int ensure_staging(hvs_ctx* c, bool dists, uint64_t nq_in, uint64_t nq_out);
+
 // query / result buffers and the batch workspace for calls of up to nq queries (hvs_reserve, hvs_query): keeps the
 // ~34 GB of per-batch state of a 2^21-query batch out of the first query's own time
 int leaf_reserve(hvs_ctx* c, uint32_t nq)
@@ -1417,6 +1515,8 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     if (nq == 0u) return HVS_OK;
     int rc = ensure_queries(c, nq);
     if (rc) return rc;
+    // pinned staging of the host path (ids only: the distance slots follow the first call that asks for distances)
+    if ((rc = ensure_staging(c, false, nq, nq))) return rc;
     // (the filter workspace only when a filter engine is going to run: 4096 <= n < 32768 under AUTO has an index for the
     // range scans of the exact engine, whose batches are kBatch queries)
     const bool filter_runs = c->have_index && (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
@@ -1487,28 +1587,51 @@ bool host_pointer_is_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-// pinned staging slots of the host pipeline, allocated on first use (4 x (27 + 26 + 26) MB)
-int ensure_staging(hvs_ctx* c, bool dists)
+// Pinned staging slots of the host pipeline, sized by the call: a call of nq_in queries (or the same volume of data rows)
+// going in and nq_out result rows coming out uses ceil(nq / 65536) slots of each ring, at most 4, each as large as its
+// piece (whole slots are 27 + 26 + 26 MB; round 3 allocated all twelve inside the first call, 6 of the 8 ms a cold call of
+// 10^4 queries took).  Pinned allocations cost ~1 ms per 25 MB: hvs_reserve makes them ahead of the first call.
+int ensure_staging(hvs_ctx* c, bool dists, uint64_t nq_in, uint64_t nq_out)
 {
+    constexpr uint32_t SQ = hvs_ctx::kStageQ;
     if (c->stage_k < c->k) {  // k grew (hvs_set_k): the result slots are too small
         for (int i = 0; i < hvs_ctx::kRing; ++i) {
             if (c->h_out_ids[i]) (void)hipHostFree(c->h_out_ids[i]);
             if (c->h_out_dists[i]) (void)hipHostFree(c->h_out_dists[i]);
             c->h_out_ids[i] = nullptr;
             c->h_out_dists[i] = nullptr;
+            c->out_cap_q[i] = c->outd_cap_q[i] = 0u;
         }
         c->stage_k = c->k;
     }
+    auto slot_q = [&](uint64_t nq, int i) -> uint32_t {  // queries slot i has to hold (0: the call does not reach it)
+        if (nq <= (uint64_t)i * SQ) return 0u;
+        const uint64_t piece = nq > (uint64_t)hvs_ctx::kRing * SQ ? SQ : std::min<uint64_t>(SQ, nq - (uint64_t)i * SQ);
+        return (uint32_t)std::min<uint64_t>(SQ, (piece + 4095u) / 4096u * 4096u);
+    };
     for (int i = 0; i < hvs_ctx::kRing; ++i) {
-        if (!c->h_in[i])
-            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_in[i]), (size_t)hvs_ctx::kStageQ * HVS_QCOLS * sizeof(float),
-                                     hipHostMallocDefault));
-        if (!c->h_out_ids[i])
-            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_ids[i]), (size_t)hvs_ctx::kStageQ * c->stage_k * sizeof(uint32_t),
-                                     hipHostMallocDefault));
-        if (dists && !c->h_out_dists[i])
-            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_dists[i]), (size_t)hvs_ctx::kStageQ * c->stage_k * sizeof(float),
-                                     hipHostMallocDefault));
+        const uint32_t qi = slot_q(nq_in, i), qo = slot_q(nq_out, i);
+        if (qi > c->in_cap_q[i]) {
+            if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
+            c->h_in[i] = nullptr;
+            c->in_cap_q[i] = 0u;
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_in[i]), (size_t)qi * HVS_QCOLS * sizeof(float), hipHostMallocDefault));
+            c->in_cap_q[i] = qi;
+        }
+        if (qo > c->out_cap_q[i]) {
+            if (c->h_out_ids[i]) (void)hipHostFree(c->h_out_ids[i]);
+            c->h_out_ids[i] = nullptr;
+            c->out_cap_q[i] = 0u;
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_ids[i]), (size_t)qo * c->stage_k * sizeof(uint32_t), hipHostMallocDefault));
+            c->out_cap_q[i] = qo;
+        }
+        if (dists && qo > c->outd_cap_q[i]) {
+            if (c->h_out_dists[i]) (void)hipHostFree(c->h_out_dists[i]);
+            c->h_out_dists[i] = nullptr;
+            c->outd_cap_q[i] = 0u;
+            HVS_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out_dists[i]), (size_t)qo * c->stage_k * sizeof(float), hipHostMallocDefault));
+            c->outd_cap_q[i] = qo;
+        }
     }
     return HVS_OK;
 }
@@ -1524,7 +1647,8 @@ int upload_rows(hvs_ctx* c, float* dst, const float* src, size_t nfloats)
         HVS_HIP(c, hipMemcpyAsync(dst, src, nfloats * sizeof(float), hipMemcpyHostToDevice, c->stream));
         return HVS_OK;
     }
-    int rc = ensure_staging(c, false);
+    // (in units of query rows: 104 floats; data rows move through the same slots)
+    int rc = ensure_staging(c, false, (nfloats + HVS_QCOLS - 1u) / HVS_QCOLS, 0u);
     if (rc) return rc;
     const size_t slot = (size_t)hvs_ctx::kStageQ * HVS_QCOLS;  // floats per slot
     size_t off = 0;
@@ -1668,13 +1792,16 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
     if (nq == 0) return HVS_OK;
     if (!q_rows || (!out_ids && !sink)) return fail(c, HVS_EINVAL, "hvs_query: q_rows / out_ids is NULL");
     const auto t_host0 = std::chrono::steady_clock::now();
+    HostTrace tr;
     int rc = leaf_begin_queries(c, nq);
     if (rc) return rc;
-    if ((rc = ensure_staging(c, out_dists != nullptr && !sink))) return rc;
-    c->nq = nq;
+    tr.mark("begin");
     const bool in_pinned = host_pointer_is_pinned(q_rows);
     // (a peer sink behaves like a pinned destination: asynchronous copies straight from the result buffer, nothing to drain)
     const bool out_pinned = sink || (host_pointer_is_pinned(out_ids) && (!out_dists || host_pointer_is_pinned(out_dists)));
+    if ((rc = ensure_staging(c, out_dists != nullptr && !sink, in_pinned ? 0u : nq, out_pinned ? 0u : nq))) return rc;
+    tr.mark("staging");
+    c->nq = nq;
     const bool sink_dists = sink && sink->want_dists;
     constexpr uint32_t SQ = hvs_ctx::kStageQ;
     constexpr int R = hvs_ctx::kRing;
@@ -1775,14 +1902,19 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         }
     };
     const Hooks hooks{send_input, copy_out_until, c, nq};
+    tr.mark("pointers");
     if ((rc = run_queries(c, 0, nq, sample_proportion, hooks, true))) return rc;
+    tr.mark("enqueued");
     if ((rc = copy_out_until(npieces))) return rc;
     while (!out_pinned && out_drained < out_enq)
         if ((rc = drain_one())) return rc;
+    tr.mark("drained");
     HVS_HIP(c, hipStreamSynchronize(c->s_out));
+    tr.mark("s_out");
     // overflowed queries: re-run by the exact engine, their rows fetched again
     const bool had_ovf = c->ovf_pending;
     if ((rc = resolve_overflow(c))) return rc;
+    tr.mark("resolved");
     if (had_ovf && (c->fallback_queries || c->retry_queries || c->demoted_queries)) {
         const uint32_t novf = c->fallback_queries, nretry = c->retry_queries, ndem = c->demoted_queries;
         std::vector<uint32_t> list((size_t)novf + nretry + ndem);
@@ -1845,6 +1977,8 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         }
     }
     c->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    tr.mark("done");
+    tr.flush("hvs_query", nq);
     return HVS_OK;
 }
 

@@ -639,7 +639,7 @@ struct HvsBatch {
     float* theta;               // [nslots] BF16 format: discard a row when its MFMA value is < theta
     int* thetai;                // same storage, INT8 format: integer threshold
     double* qn;                 // [nslots] |q|^2
-    float* normq;               // [nslots] BF16 format: |q| (rounded up); INT8 formats: the band's clip term (hvs_k_prep_slots)
+    float* normq;               // [nslots] BF16 format: |q| (rounded up); INT8 formats: the band's clip term (hvs_k_prep)
     float* eq;                  // [nslots] |q - bf16(q)| (rounded up)
     float* nqb;                 // [nslots] |bf16(q)| (rounded up)
     // top-k state
@@ -791,7 +791,8 @@ __global__ void hvs_k_count_classes(const float* __restrict__ Q, uint32_t q0, ui
 // no host round trip
 __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint32_t nq, const uint32_t* __restrict__ list,
                                   const uint64_t* __restrict__ keys_ct, const uint64_t* __restrict__ keys_t, uint32_t n,
-                                  const uint32_t* __restrict__ counts, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+                                  const uint32_t* __restrict__ counts, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                  uint32_t* __restrict__ qa, uint32_t* __restrict__ qb)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
@@ -800,6 +801,10 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
     const uint32_t rk = hvs_type_rank(p.type);
     uint32_t a, b;
     hvs_query_range(p, keys_ct, keys_t, n, a, b);
+    // the range travels with the batch-local index (the sort's payload): hvs_k_layout hands it to the query's slot, so the
+    // two binary searches are done once per query and batch
+    qa[i] = a;
+    qb[i] = b;
 #if HVS_BIN_QUERIES
     uint32_t nbins = counts[rk] / HVS_BIN_QUERIES;
 #else
@@ -824,19 +829,22 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
         const uint32_t a16 = (uint32_t)(((uint64_t)a << 16) / ((uint64_t)n + 1ull)), b16 = (uint32_t)(((uint64_t)b << 16) / ((uint64_t)n + 1ull));
         (void)abin;
         keys[i] = ((uint64_t)rk << 61) | ((uint64_t)((spread(a16) << 1) | spread(b16)) << 16) | (uint64_t)(b & 0xFFFFu);
-        idx[i] = qi;
+        idx[i] = i;
         return;
     }
 #endif
     keys[i] = ((uint64_t)rk << 61) | ((uint64_t)abin << 32) | (uint64_t)b;
-    idx[i] = qi;
+    idx[i] = i;
 }
 
 // Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole quad of
 // groups (a filter workgroup serves one quad and one ordering), the type-2 part to a whole group.  One thread block; writes the slot -> query map.
 // layout[0..4] = first slot of each class rank, layout[5] = nslots used, layout[6] = first group of T part
+// `sorted_idx` holds batch-local indices i: the query is list[i] (retry batches) or q0 + i, its position range qa[i], qb[i]
 __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
-                             uint32_t nq, uint32_t nslots_cap, uint32_t* __restrict__ qid, uint32_t* __restrict__ rank,
+                             uint32_t nq, uint32_t nslots_cap, uint32_t q0, const uint32_t* __restrict__ list,
+                             const uint32_t* __restrict__ qa, const uint32_t* __restrict__ qb, uint32_t* __restrict__ qid,
+                             uint32_t* __restrict__ rank, uint32_t* __restrict__ ra, uint32_t* __restrict__ rb,
                              uint32_t* __restrict__ layout)
 {
     __shared__ uint32_t first[6];   // first sorted index of each rank (first[5] = nq)
@@ -871,12 +879,21 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
         const uint32_t off = s - slot0[rk];
         const uint32_t cnt = first[rk + 1] - first[rk];
         const bool used = s < slot0[5] && off < cnt;
-        qid[s] = used ? sorted_idx[first[rk] + off] : 0xFFFFFFFFu;
+        const uint32_t li = used ? sorted_idx[first[rk] + off] : 0u;
+        qid[s] = used ? (list ? list[li] : q0 + li) : 0xFFFFFFFFu;
+        ra[s] = used ? qa[li] : 0u;
+        rb[s] = used ? qb[li] : 0u;
         rank[s] = rk;
     }
 }
 
-// per slot: position range of the predicate, norms, bound inputs; resets the top-k state
+// hvs_k_prep -- one 512-thread block per group of 128 slots (round 4: the per-slot and the per-group preparation were two
+// kernels, the first with ONE lane per slot walking the query's 100 dimensions and repeating the binary searches of
+// hvs_k_query_keys2: 45 + 25 us of a 10^4-query batch whose whole step is 1.9 ms).
+//   per slot (4 lanes, 25 dimensions each, f64 partial sums joined by two shuffles): norms and bound inputs of the query,
+//   top-k state reset; the position range comes from hvs_k_layout;
+//   per group: union of the slots' ranges, ordering, cleared entry counters;
+//   per group: the B-operand fragments of its 128 queries in the tile format `fmt`.
 //
 // INT8 formats, queries outside the data's bounding box: a coordinate beyond +-127 sd is clipped to +-127, and the part
 // that was cut off, c_k = |q'_k| - 127 sd, multiplies a row coordinate |d'_k| <= H_k (the box's half width in that
@@ -884,26 +901,29 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
 // dimensions only.  The sum is kept per slot (`normq`, which the INT8 band does not use otherwise) and hvs_k_merge adds it
 // to the band: a query a little outside the box costs a wider band, not the exact engine.  Far outside (the clip term
 // above 4x the rest of the band) the filter would let most rows through: the exact engine answers.
-__global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const uint64_t* __restrict__ keys_ct,
-                                 const uint64_t* __restrict__ keys_t, uint32_t n, int count_pairs,
-                                 unsigned long long* __restrict__ counters, int fmt, const HvsQuant* __restrict__ qz,
-                                 const HvsBounds* __restrict__ bounds, int for_filter)
+__global__ __launch_bounds__(4 * HVS_GROUP) void hvs_k_prep(const float* __restrict__ Q, HvsBatch B, int count_pairs,
+                                                            unsigned long long* __restrict__ counters, int fmt,
+                                                            const HvsQuant* __restrict__ qz, const HvsBounds* __restrict__ bounds,
+                                                            int for_filter)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B.nslots) return;
+    __shared__ uint32_t smin[HVS_GROUP], smax[HVS_GROUP];
+    __shared__ unsigned long long spairs;
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t sl = t >> 2, part = t & 3u;  // slot within the group; quarter of the dimensions
+    const uint32_t s = g * HVS_GROUP + sl;
     const uint32_t qi = B.qid[s];
-    uint32_t a = 0, b = 0;
+    uint32_t a = B.ra[s], b = B.rb[s];          // the predicate's position range (hvs_k_query_keys2 -> hvs_k_layout)
+    if (t == 0u) spairs = 0ull;
     double qn = 0.0, e2 = 0.0, nb2 = 0.0, clipband = 0.0;
-    bool hopeless = false;
+    int bad = 0;
+    constexpr int kPart = HVS_NDIM / 4;
     if (qi != 0xFFFFFFFFu) {
-        const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS;
-        const HvsQParams p = hvs_parse_query(q);
-        hvs_query_range(p, keys_ct, keys_t, n, a, b);
+        const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS + 4;
         if (HVS_IS_I8(fmt)) {
             // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2 over the unclipped dimensions
             const double sd = qz->sd, inv_sd = qz->inv_sd;
-            for (int k = 0; k < HVS_NDIM; ++k) {
-                const double x = (double)q[4 + k] - (double)qz->center[k];
+            for (int k = (int)part * kPart; k < (int)(part + 1u) * kPart; ++k) {
+                const double x = (double)q[k] - (double)qz->center[k];
                 const double xq = sd * (double)hvs_quant_i8(x, inv_sd);
                 qn += x * x;
                 nb2 += xq * xq;
@@ -914,59 +934,63 @@ __global__ void hvs_k_prep_slots(const float* __restrict__ Q, HvsBatch B, const 
                     const double lo = fabs((double)hvs_attr_key_inv(qz->kmin[k]) - c), hi = fabs((double)hvs_attr_key_inv(qz->kmax[k]) - c);
                     clipband += fabs(x - xq) * (lo > hi ? lo : hi) * (1.0 + 1e-9);
                 } else {
-                    hopeless = true;  // NaN component
+                    bad = 1;  // NaN component
                 }
             }
-            const double rest = sqrt(nb2) * (double)bounds->e_d8 + sqrt(e2) * (double)bounds->n_d8;
-            if (!(clipband <= 4.0 * rest)) hopeless = true;
         } else {
-            for (int k = 0; k < HVS_NDIM; ++k) {
-                const float x = q[4 + k];
+            for (int k = (int)part * kPart; k < (int)(part + 1u) * kPart; ++k) {
+                const float x = q[k];
                 const float xb = hvs_h16_to_f32(fmt, hvs_h16_bits(fmt, x));
                 qn += (double)x * (double)x;
                 e2 += ((double)x - (double)xb) * ((double)x - (double)xb);
                 nb2 += (double)xb * (double)xb;
             }
-            if (fmt == HVS_FMT_F16) {
+        }
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {  // the slot's 4 lanes are neighbours in the wave
+        qn += __shfl_xor(qn, o);
+        e2 += __shfl_xor(e2, o);
+        nb2 += __shfl_xor(nb2, o);
+        clipband += __shfl_xor(clipband, o);
+        bad |= __shfl_xor(bad, o);
+    }
+    __syncthreads();  // (spairs is cleared)
+    if (part == 0u) {
+        bool hopeless = bad != 0;
+        if (qi != 0xFFFFFFFFu) {
+            if (HVS_IS_I8(fmt)) {
+                const double rest = sqrt(nb2) * (double)bounds->e_d8 + sqrt(e2) * (double)bounds->n_d8;
+                if (!(clipband <= 4.0 * rest)) hopeless = true;
+            } else if (fmt == HVS_FMT_F16) {
                 e2 = (sqrt(e2) + HVS_F16_FLUSH) * (sqrt(e2) + HVS_F16_FLUSH);  // (possible denormal flush, see HVS_F16_FLUSH)
                 if (!(nb2 < 1.0e9)) hopeless = true;                           // a component beyond the half-precision range
             }
+            if (count_pairs && b > a) atomicAdd(&spairs, (unsigned long long)(b - a));
         }
-        if (count_pairs) atomicAdd(&counters[0], (unsigned long long)(b - a));
+        // a query without a usable bound (non-finite components, far outside the data's box) is answered by the exact engine
+        // and takes no part in the filter (empty range)
+        if (!(qn < 1.0e30)) hopeless = true;
+        if (qi == 0xFFFFFFFFu || !for_filter) hopeless = false;  // (the exact engine's range scans use the ranges only)
+        if (hopeless) a = b = 0u;
+        B.ra[s] = a;
+        B.rb[s] = b;
+        B.qn[s] = qn;
+        B.normq[s] = HVS_IS_I8(fmt) ? (clipband > 0.0 ? hvs_round_up_f32(clipband) : 0.0f) : hvs_round_up_f32(sqrt(qn) * (1.0 + 1e-9) + 1e-30);
+        B.eq[s] = hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30);
+        B.nqb[s] = hvs_round_up_f32(sqrt(nb2) * (1.0 + 1e-9) + 1e-30);
+        B.topcnt[s] = 0;
+        B.candcnt[s] = 0;
+        B.overflow[s] = hopeless ? HVS_FAIL_EXACT : 0u;
+        B.tau[s] = __builtin_inff();
+        // -inf: everything in range is a candidate until a threshold is set; +inf: nothing can ever match
+        if (HVS_IS_I8(fmt))
+            B.thetai[s] = b > a ? (int)0x80000000 : 0x7FFFFFFF;
+        else
+            B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
+        smin[sl] = a < b ? a : 0xFFFFFFFFu;
+        smax[sl] = a < b ? b : 0u;
     }
-    // a query without a usable bound (non-finite components, far outside the data's box) is answered by the exact engine
-    // and takes no part in the filter (empty range)
-    if (!(qn < 1.0e30)) hopeless = true;
-    if (qi == 0xFFFFFFFFu || !for_filter) hopeless = false;  // (the exact engine's range scans use the ranges only)
-    if (hopeless) a = b = 0u;
-    B.ra[s] = a;
-    B.rb[s] = b;
-    B.qn[s] = qn;
-    B.normq[s] = HVS_IS_I8(fmt) ? (clipband > 0.0 ? hvs_round_up_f32(clipband) : 0.0f) : hvs_round_up_f32(sqrt(qn) * (1.0 + 1e-9) + 1e-30);
-    B.eq[s] = hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30);
-    B.nqb[s] = hvs_round_up_f32(sqrt(nb2) * (1.0 + 1e-9) + 1e-30);
-    B.topcnt[s] = 0;
-    B.candcnt[s] = 0;
-    B.overflow[s] = hopeless ? HVS_FAIL_EXACT : 0u;
-    B.tau[s] = __builtin_inff();
-    // -inf: everything in range is a candidate until a threshold is set; +inf: nothing can ever match
-    if (HVS_IS_I8(fmt))
-        B.thetai[s] = b > a ? (int)0x80000000 : 0x7FFFFFFF;
-    else
-        B.theta[s] = b > a ? -__builtin_inff() : __builtin_inff();
-}
-
-// per group: union of the slots' ranges, ordering; per block: BF16 B-operand fragments.
-// One 128-thread block per group.
-__global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __restrict__ Q, HvsBatch B, int fmt,
-                                                               const HvsQuant* __restrict__ qz)
-{
-    __shared__ uint32_t smin[HVS_GROUP], smax[HVS_GROUP];
-    const uint32_t g = blockIdx.x, t = threadIdx.x;
-    const uint32_t s = g * HVS_GROUP + t;
-    const uint32_t a = B.ra[s], b = B.rb[s];
-    smin[t] = a < b ? a : 0xFFFFFFFFu;
-    smax[t] = a < b ? b : 0u;
     __syncthreads();
     for (uint32_t w = HVS_GROUP / 2; w > 0; w >>= 1) {
         if (t < w) {
@@ -982,27 +1006,28 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
         B.gord[g] = B.rank[g * HVS_GROUP] == 4u ? 1u : 0u;
         B.paircnt[g] = 0;
         B.goverflow[g] = 0;
+        if (count_pairs && spairs) atomicAdd(&counters[0], spairs);
     }
     if (fmt == HVS_FMT_I8X16) {
         // B fragments of v_mfma_i32_16x16x64_i8: fragment (sub-block j of 16 queries, k-step ks): lane l holds query
         // column 16 j + (l & 15), k = 64 ks + 16 (l >> 4) + 0..15; stored [group][j][ks][lane]
         const double inv_sd = qz->inv_sd;
         constexpr uint32_t kSub = HVS_GROUP / HVS_I8X16_QSUB;
-        for (uint32_t e = t; e < kSub * 2u * 64u; e += HVS_GROUP) {
+        for (uint32_t e = t; e < kSub * 2u * 64u; e += blockDim.x) {
             const uint32_t j = e / 128u, ks = (e / 64u) & 1u, l = e & 63u;
             const uint32_t slot = g * HVS_GROUP + j * HVS_I8X16_QSUB + (l & 15u);
-            const uint32_t qi = B.qid[slot];
+            const uint32_t qj = B.qid[slot];
             uint32_t w[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 uint32_t word = 0;
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    const int k = 64 * (int)ks + 16 * (int)(l >> 4) + 4 * p + e2;
+                for (int e2i = 0; e2i < 4; ++e2i) {
+                    const int k = 64 * (int)ks + 16 * (int)(l >> 4) + 4 * p + e2i;
                     int v = 0;
-                    if (qi != 0xFFFFFFFFu && k < HVS_NDIM)
-                        v = hvs_quant_i8((double)Q[(size_t)qi * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
-                    word |= ((uint32_t)v & 0xFFu) << (8 * e2);
+                    if (qj != 0xFFFFFFFFu && k < HVS_NDIM)
+                        v = hvs_quant_i8((double)Q[(size_t)qj * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
+                    word |= ((uint32_t)v & 0xFFu) << (8 * e2i);
                 }
                 w[p] = word;
             }
@@ -1013,23 +1038,23 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
     if (fmt == HVS_FMT_I8) {
         // INT8 B fragments: lane l of k-step ks holds query column (l & 31), k = 32 ks + 16 (l >> 5) + 0..15
         const double inv_sd = qz->inv_sd;
-        for (uint32_t e = t; e < HVS_QB * HVS_I8_KSTEPS * 64u; e += HVS_GROUP) {
+        for (uint32_t e = t; e < HVS_QB * HVS_I8_KSTEPS * 64u; e += blockDim.x) {
             const uint32_t qb = e / (HVS_I8_KSTEPS * 64u);
             const uint32_t ks = (e / 64u) % HVS_I8_KSTEPS;
             const uint32_t l = e & 63u;
             const uint32_t slot = g * HVS_GROUP + qb * 32u + (l & 31u);
-            const uint32_t qi = B.qid[slot];
+            const uint32_t qj = B.qid[slot];
             uint32_t w[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 uint32_t word = 0;
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    const int k = 32 * (int)ks + 16 * (int)(l >> 5) + 4 * p + e2;
+                for (int e2i = 0; e2i < 4; ++e2i) {
+                    const int k = 32 * (int)ks + 16 * (int)(l >> 5) + 4 * p + e2i;
                     int v = 0;
-                    if (qi != 0xFFFFFFFFu && k < HVS_NDIM)
-                        v = hvs_quant_i8((double)Q[(size_t)qi * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
-                    word |= ((uint32_t)v & 0xFFu) << (8 * e2);
+                    if (qj != 0xFFFFFFFFu && k < HVS_NDIM)
+                        v = hvs_quant_i8((double)Q[(size_t)qj * HVS_QCOLS + 4 + k] - (double)qz->center[k], inv_sd);
+                    word |= ((uint32_t)v & 0xFFu) << (8 * e2i);
                 }
                 w[p] = word;
             }
@@ -1038,27 +1063,27 @@ __global__ __launch_bounds__(HVS_GROUP) void hvs_k_prep_groups(const float* __re
         return;
     }
     // B fragments: lane l of k-step ks holds query column (l & 31), k = 16 ks + 8 (l >> 5) + 0..7
-    for (uint32_t e = t; e < HVS_QB * HVS_KSTEPS * 64u; e += HVS_GROUP) {
+    for (uint32_t e = t; e < HVS_QB * HVS_KSTEPS * 64u; e += blockDim.x) {
         const uint32_t qb = e / (HVS_KSTEPS * 64u);
         const uint32_t ks = (e / 64u) % HVS_KSTEPS;
         const uint32_t l = e & 63u;
         const uint32_t slot = g * HVS_GROUP + qb * 32u + (l & 31u);
-        const uint32_t qi = B.qid[slot];
+        const uint32_t qj = B.qid[slot];
         uint32_t w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             uint16_t v2[2];
 #pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int k = 16 * (int)ks + 8 * (int)(l >> 5) + 2 * p + e2;
+            for (int e2i = 0; e2i < 2; ++e2i) {
+                const int k = 16 * (int)ks + 8 * (int)(l >> 5) + 2 * p + e2i;
                 uint16_t v = 0;
-                if (qi != 0xFFFFFFFFu) {
+                if (qj != 0xFFFFFFFFu) {
                     if (k < HVS_NDIM)
-                        v = hvs_h16_bits(fmt, Q[(size_t)qi * HVS_QCOLS + 4 + k]);
+                        v = hvs_h16_bits(fmt, Q[(size_t)qj * HVS_QCOLS + 4 + k]);
                     else if (k < 103)
                         v = fmt == HVS_FMT_F16 ? 0x3C00 : 0x3F80;  // 1.0: multiplies the three -|d|^2/2 pieces
                 }
-                v2[e2] = v;
+                v2[e2i] = v;
             }
             w[p] = (uint32_t)v2[0] | ((uint32_t)v2[1] << 16);
         }
@@ -1898,14 +1923,14 @@ struct HvsSegs {
 // Segment size per level: HVS_SEG blocks where the batch has enough quads to fill the chip, smaller (down to one LDS
 // stage of 8 tiles) for small batches, so that a level of T blocks still makes ~4 work items per workgroup slot:
 // with 10^4 queries (20 quads) a fixed 256-block segment left the lower levels of D = 10^6 with 20 items for 512 slots.
-static inline HvsSegs hvs_make_segs(const HvsLevels& L, uint32_t nquads, uint32_t wg_slots)
+static inline HvsSegs hvs_make_segs(const HvsLevels& L, uint32_t nquads, uint32_t wg_slots, uint32_t items_per_slot = 4u)
 {
     HvsSegs S{};
     S.K = L.K;
     uint32_t t = 0;
     for (uint32_t j = 0; j <= L.K; ++j) {
         const uint64_t T = L.off[j + 1] - L.off[j];
-        uint64_t want = T * (uint64_t)(nquads ? nquads : 1u) / (4ull * (wg_slots ? wg_slots : 1u));
+        uint64_t want = T * (uint64_t)(nquads ? nquads : 1u) / ((uint64_t)(items_per_slot ? items_per_slot : 1u) * (wg_slots ? wg_slots : 1u));
         uint32_t seg = 8u;
         while (seg < HVS_SEG && (uint64_t)seg * 2u <= want) seg *= 2u;
         S.seg[j] = seg;
@@ -2556,6 +2581,9 @@ __device__ __forceinline__ uint32_t hvs_guess_m(const HvsLevels& L, const HvsGue
                                                 uint32_t knn)
 {
     if (level == L.K && G.last_m) return G.last_m < knn ? G.last_m : knn;
+    // a range of k rows or fewer can never hold k rows below any threshold: a guess there buys nothing (every row of the range
+    // is kept anyway) and the final check `k keys held` would send the query to a retry batch
+    if (b - a <= knn) return knn;
     const uint32_t seen = hvs_rows_seen_before(L, level, a, b);
     if (seen == 0u || b <= a) return knn;
     const float lf = __log2f((float)(b - a) / (float)seen);  // -log2 F >= 0
@@ -2624,7 +2652,10 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
     uint64_t* buf = sbuf[w];
     uint32_t m = B.candcnt[slot];
     if (m > B.fcap) m = B.fcap;
-    if (m == 0u && !FINAL) return;  // nothing new at this level: top-k, tau and theta stand
+    // nothing new at this level: top-k, tau and theta stand.  (tau is not re-derived for `level_next` from the keys held: the
+    // order statistic only grows from level to level, so the m_next-th smallest of an unchanged list is >= the tau already
+    // set, and tau never increases -- min(tau, .) would return tau.)
+    if (m == 0u && !FINAL) return;
     uint32_t cnt = B.topcnt[slot];
     for (uint32_t e = lane; e < cnt; e += 64u) buf[e] = B.top[(size_t)slot * B.topcap + e];
     const uint64_t* __restrict__ lst = B.cand + (size_t)slot * B.fcap;
@@ -2675,7 +2706,7 @@ __global__ __launch_bounds__(256) void hvs_k_merge(const float* __restrict__ D, 
                 if (cut) {
                     const double g = 20.0 * 5.9604644775390625e-08;
                     const double iu = qz->inv_sd * qz->inv_sd;  // 1 / sd^2
-                    // (normq: the clip term of a query outside the data's box, see hvs_k_prep_slots)
+                    // (normq: the clip term of a query outside the data's box, see hvs_k_prep)
                     const double band = ((double)B.nqb[slot] * (double)bounds->e_d8 + (double)B.eq[slot] * (double)bounds->n_d8 +
                                          (double)B.normq[slot]) * (1.0 + 1e-6);
                     // -2: one unit for nh = floor(.), one for the f64 evaluation of this expression (relative

@@ -13,7 +13,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
     t0 = time.time()
     r = subprocess.run([PKG.cli_path(), d, q, o], capture_output=True, text=True)
     wall = time.time() - t0
-    print([l for l in r.stderr.splitlines() if "Vector Search took" in l], f"process wall {wall:.2f} s")
+    print([l for l in r.stderr.splitlines() if "Vector Search took" in l or "hvs trace" in l], f"process wall {wall:.2f} s")
     ids = T.read_knn(o)
     sel = np.arange(0, nq, max(1, nq // 64))
     ref, _ = T.oracle_query(nodes, queries[sel], threads=16)

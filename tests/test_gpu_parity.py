@@ -1087,3 +1087,76 @@ def test_data_sharded_mode_with_another_k(k):
     with T.oracle_k(k):
         ref, refd = T.oracle_query(nodes, queries)
     assert np.array_equal(ids, ref) and np.array_equal(dists.view(np.uint32), refd.view(np.uint32))
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]], ids=["one_gpu", "two_virtual_ranks"])
+def test_format_change_then_a_smaller_call_on_the_same_context(devices):
+    """the list of queries a mid-call change of tile format moved aside must die with its call.  A call far
+    outside the data's box (FORMAT_CHANGED), then a much smaller call on the same context: the small call's rows -- and nothing
+    past them: the result arrays sit inside guarded buffers -- equal the exact engine's."""
+    n, nq, small = 200_000, 6000, 700
+    nodes = T.gen_data(n, 81, T.GEN_V1, 10)
+    inside = T.gen_queries(nq, 82, T.GEN_V1, 10)
+    outside = inside.copy()
+    outside[:, 4:] *= np.float32(3.0)
+    with PKG.Engine(0) as x:
+        x.set_engine(PKG.ENGINE_EXACT_SCAN)
+        x.load_data(nodes)
+        want_out = x.query(outside, 1.0)
+        want_small = x.query(inside[:small], 1.0)
+    with (PKG.Engine(devices=devices) if devices else PKG.Engine(0)) as e:
+        e.load_data(nodes)
+        ids, d = e.query(outside, 1.0)
+        t = e.last_timing()
+        assert t.flags & 2, t.as_dict()
+        assert np.array_equal(ids, want_out[0]) and np.array_equal(d.view(np.uint32), want_out[1].view(np.uint32))
+        guard = 4096
+        buf_i = np.full((small + guard, 100), 0xDEADBEEF, np.uint32)
+        buf_d = np.full((small + guard, 100), -7.0, np.float32)
+        e.query(inside[:small], 1.0, out_ids=buf_i[:small], out_dists=buf_d[:small])
+        t2 = e.last_timing()
+        assert t2.flags == 0 and t2.nq == small
+        assert np.array_equal(buf_i[:small], want_small[0]) and np.array_equal(buf_d[:small].view(np.uint32), want_small[1].view(np.uint32))
+        assert np.all(buf_i[small:] == 0xDEADBEEF) and np.all(buf_d[small:] == -7.0), "a stale list of the earlier call was scattered past the result"
+
+
+def test_one_context_many_calls_fuzz():
+    """per-context state survives between calls (tile format, guess tables keyed by k, candidate capacities, lists of
+    re-run queries).  ONE context answers a sequence of calls with varying nq, k, sample_proportion, engine and API (host /
+    resident), with a call far outside the data's box in the middle; every call is compared bit for bit with a fresh exact
+    engine."""
+    n = 150_000
+    rng = np.random.default_rng(20261005)
+    nodes = T.gen_data(n, 91, T.GEN_V1, 10)
+    pool = T.gen_queries(40_000, 92, T.GEN_V1, 10)
+    far = pool[:5000].copy()
+    far[:, 4:] *= np.float32(3.0)
+    plan = []
+    for step in range(14):
+        nq = int(rng.choice([1, 37, 512, 3000, 9000, 20000]))
+        q0 = int(rng.integers(0, len(pool) - nq))
+        plan.append(dict(q=pool[q0:q0 + nq], k=int(rng.choice([100, 100, 100, 10, 200])), sp=float(rng.choice([1.0, 1.0, 0.6, 0.3])),
+                         engine=int(rng.choice([0, 0, 0, 3, 4, 2, 1])), resident=bool(rng.integers(0, 2))))
+    plan.insert(5, dict(q=far, k=100, sp=1.0, engine=0, resident=False))           # FORMAT_CHANGED in mid-sequence
+    plan.insert(6, dict(q=pool[100:100 + 300], k=100, sp=1.0, engine=0, resident=False))
+    with PKG.Engine(0) as x, PKG.Engine(0) as e:
+        x.set_engine(PKG.ENGINE_EXACT_SCAN)
+        x.load_data(nodes)
+        e.load_data(nodes)
+        for i, st in enumerate(plan):
+            x.set_k(st["k"])
+            want_i, want_d = x.query(st["q"], st["sp"])
+            e.set_k(st["k"])
+            e.set_engine(st["engine"])
+            if st["resident"]:
+                e.upload_queries(st["q"])
+                e.query_resident(0, len(st["q"]), st["sp"])
+                e.sync()
+                ids, d = e.download_results(0, len(st["q"]))
+            else:
+                ids, d = e.query(st["q"], st["sp"])
+            t = e.last_timing()
+            bad = np.nonzero((ids != want_i).any(axis=1) | (d.view(np.uint32) != want_d.view(np.uint32)).any(axis=1))[0]
+            assert bad.size == 0, (i, {k: v for k, v in st.items() if k != "q"}, len(st["q"]), bad[:8], t.as_dict())
+            print("call", i, "nq", len(st["q"]), {k: v for k, v in st.items() if k != "q"}, "ran", t.engine, "flags", t.flags,
+                  "retried", t.retry_queries, "exact", t.fallback_queries)
