@@ -112,6 +112,11 @@ def main():
     ap.add_argument("--no-fixed-q", action="store_true",
                     help="skip the fixed-Q leg (rank 0's share of the 4x10^6-query set at 1, 2, 4, 8 GPUs, run on this GPU)")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--in-library", action="store_true",
+                    help="also time the library's own multi-GPU context (hvs_create_multi: one process, all GPUs) on the 4x10^6-query set")
+    ap.add_argument("--in-library-devices", default="", help="device list of that context, e.g. 0,0,0,0 (virtual ranks on one GPU)")
+    ap.add_argument("--per-step-calls", action="store_true",
+                    help="N = 1: one library call per step with a synchronisation behind it (round 3's timed region; A/B)")
     ap.add_argument("--no-configs12", action="store_true", help="skip the BASELINE configs[1]/[2] leg (D = 10^6, Q = 10^4 on one GPU)")
     ap.add_argument("--only-configs12", action="store_true", help="run only that leg and print its object")
     ap.add_argument("--force-dist", action="store_true",
@@ -161,41 +166,58 @@ def main():
     assert q_last - q_first == a.batch * total_batches
     eng.gen_queries(a.batch * total_batches, T.SEED_QUERY, a.profile, 100, a.force_type, first_row=q_first)
 
-    # result gather (N > 1): every rank's block of ids goes to rank 0 over xGMI (RCCL gather; rank 0 alone needs the
-    # output.bin rows).  Two send buffers alternate, so a step never waits for the previous step's gather.
-    ids_dev = [torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(2)] if use_dist else None
+    # Timed region.  The K timed steps are a few library calls over several batches each (the W warm-up steps another): the
+    # library runs consecutive batches of a call on two lanes, so that a batch's preparation and low levels share the chip with
+    # the previous batch's last re-scoring and final merge -- a pipeline a driver that synchronised after every batch would
+    # break.  N = 1: ONE call over the K batches.  N > 1: calls of ~K/4 batches; after each call every batch's block of ids
+    # is exported and gathered to rank 0 over xGMI (RCCL gather on torch's stream: rank 0 alone needs the output.bin rows)
+    # while the next call computes -- only the last call's gathers are exposed.
+    chunk = a.steps if not use_dist else max(1, a.steps // 4)
+    if a.per_step_calls:
+        chunk = 1
+    ids_dev = [torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(min(a.steps, 2 * chunk))] if use_dist else None
     gathered = ([torch.empty((a.batch, K), dtype=torch.int32, device="cuda") for _ in range(world)]
                 if use_dist and rank == 0 else None)
+    gather_done = [None] * (len(ids_dev) if ids_dev else 0)            # event after the gather that last read each send buffer
+    gathered_bytes = 0
 
-    gather_done = [None, None]                                         # event after the gather that last read each send buffer
+    def run_call(b0, nb):
+        """batches [b0, b0 + nb) as one library call; results final (failed guesses re-run) when it returns"""
+        eng.query_resident(b0 * a.batch, nb * a.batch, 1.0)            # asynchronous on the library's streams
+        eng.sync()
 
-    def step(b):
-        eng.query_resident(b * a.batch, a.batch, 1.0)                  # asynchronous on the library's stream
-        if use_dist:
-            buf = ids_dev[b & 1]
-            if gather_done[b & 1] is not None:
-                gather_done[b & 1].synchronize()                       # (two steps old: long done; keeps the buffer reuse honest)
-            eng.export_results_device(b * a.batch, a.batch, buf.data_ptr())
+    def gather_call(b0, nb):
+        nonlocal gathered_bytes
+        for b in range(b0, b0 + nb):
+            k = b % len(ids_dev)
+            if gather_done[k] is not None:
+                gather_done[k].synchronize()                           # (2 x chunk steps old: long done; keeps the buffer reuse honest)
+            eng.export_results_device(b * a.batch, a.batch, ids_dev[k].data_ptr())
             eng.stream_wait(torch.cuda.current_stream().cuda_stream)   # stream-ordered hand-off to the collective's stream
-            dist.gather(buf, gathered, dst=0)                          # RCCL, asynchronous on torch's stream
-            gather_done[b & 1] = torch.cuda.Event()
-            gather_done[b & 1].record()
-        else:
-            eng.sync()
+            dist.gather(ids_dev[k], gathered, dst=0)                   # RCCL, asynchronous on torch's stream
+            gather_done[k] = torch.cuda.Event()
+            gather_done[k].record()
+            gathered_bytes += (world - 1) * a.batch * K * 4
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for b in range(a.warmup):
-        step(b)
+    if a.warmup:
+        run_call(0, a.warmup)
+        if use_dist:
+            gather_call(a.warmup - 1, 1)                               # (the collective's first use: outside the timed region)
     kern_ms, kern_launches, pairs, scanned, query_ms, rescored, fallback, untimed, retried = 0.0, 0, 0, 0, 0.0, 0, 0, 0, 0
+    gathered_bytes = 0
+    calls = 0
     fence()
     t0 = time.perf_counter()
-    for b in range(a.warmup, total_batches):
-        step(b)
-        tm = eng.last_timing()                                          # HIP events on the library's stream
+    for b0 in range(a.warmup, total_batches, chunk):
+        nb = min(chunk, total_batches - b0)
+        run_call(b0, nb)
+        calls += 1
+        tm = eng.last_timing()                                          # HIP events on the library's streams
         kern_ms += tm.main_kernel_ms
         kern_launches += tm.main_kernel_launches
         pairs += tm.pairs
@@ -205,12 +227,17 @@ def main():
         fallback += tm.fallback_queries
         untimed += tm.untimed_launches
         retried += tm.retry_queries
+        if use_dist:
+            gather_call(b0, nb)                                         # runs under the next call's compute
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = elapsed * 1e3
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tmin = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        elapsed, rank_ms_min = float(tt.item()), float(tmin.item()) * 1e3
     engine_id = int(eng.last_timing().engine)
     if use_dist and rank == 0 and world == 1:                          # --force-dist rehearsal: the gathered block is the local one
         got = eng.download_results((total_batches - 1) * a.batch, a.batch, want_dists=False)
@@ -250,6 +277,7 @@ def main():
                                    f"k=100, sample_proportion=1",
                        "profile": a.profile,
                        "n": a.n, "queries_per_step_per_gpu": a.batch, "engine": engine_id,
+                       "timed_region": f"{calls} library call(s) of up to {chunk} batches each (consecutive batches of a call run on two lanes)",
                        "sharding": "Q partitioned across ranks, D replicated, RCCL gather of the ids to rank 0"},
             "roofline": {"bound": "mfma" if engine_id in (2, 3, 4) else "valu-fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
@@ -278,7 +306,14 @@ def main():
                          "measured_bare_chain_ceiling_random_operands_tflops": {3: 4010.0}.get(engine_id),
                          "fallback_queries": fallback, "retry_queries": retried},
             "load_s": load_s,
+            # dtype "f32" names the arithmetic that decides every answer (exact-order f32 re-scoring, optimized_impl.h:96-125);
+            # the timed dominant kernel (roofline.kernel) filters in `filter_dtype` and is priced against THAT type's peak
+            "filter_dtype": {2: "bf16", 3: "int8", 4: "f16"}.get(engine_id, "f32"),
         }
+        if use_dist:
+            out["collective"] = {"backend": "nccl (RCCL)", "rccl_ranks": dist.get_world_size(), "op": "gather of each step's ids to rank 0",
+                                 "gathered_bytes": gathered_bytes, "library_calls": calls,
+                                 "rank_ms_max": elapsed * 1e3, "rank_ms_min": rank_ms_min}
 
     # ---- end-to-end leg: the reference's own timing scope (src/test.cpp:82-88: queries in host RAM -> ids in host
     # RAM).  The same a.steps batches as ONE hvs_query call from ordinary (pageable) host memory through the library's
@@ -342,6 +377,55 @@ def main():
             del q_host, ids_host, ids_res
         out["fixed_q"] = fixed
 
+    # ---- fixed-Q leg at N > 1 (strong scaling; BASELINE's metric is ONE query set of 4x10^6, src/test.cpp:82-92): every rank takes
+    # its contiguous share (sharding.shard_range) FROM HOST MEMORY -- upload, one resident call, export -- and the ids are gathered
+    # to rank 0 over RCCL inside the timed region; rank 0 then checks a sampled slice of every rank's share against its own
+    # recomputation of those queries.
+    if use_dist and not a.no_fixed_q and a.n == 10_000_000 and a.profile == 1:
+        QSET = 4_000_000
+        f0, f1 = sharding.shard_range(QSET, rank, world)
+        share, max_share = f1 - f0, -(-QSET // world)
+        eng.gen_queries(share, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, first_row=f0)
+        q_host = eng.download_queries(0, share)                           # this rank's slice of the query file, in host memory
+        send = torch.zeros((max_share, K), dtype=torch.int32, device="cuda")
+        recv = [torch.empty((max_share, K), dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+        eng.upload_queries(q_host[: min(share, 65536)])                   # warm-up of the path
+        eng.query_resident(0, min(share, 65536), 1.0)
+        eng.sync()
+        fence()
+        t1 = time.perf_counter()
+        eng.upload_queries(q_host)                                        # host -> device (pageable buffer, the library's staging)
+        eng.query_resident(0, share, 1.0)
+        eng.export_results_device(0, share, send.data_ptr())
+        eng.stream_wait(torch.cuda.current_stream().cuda_stream)
+        dist.gather(send, recv, dst=0)
+        torch.cuda.synchronize()
+        local_s = time.perf_counter() - t1
+        fence()
+        fq_s = time.perf_counter() - t1
+        tm = eng.last_timing()
+        tt = torch.tensor([fq_s, local_s, -local_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        fq_s, local_max, local_min = float(tt[0]), float(tt[1]), -float(tt[2])
+        if rank == 0:
+            checked = 0
+            for r in range(world):
+                r0, r1 = sharding.shard_range(QSET, r, world)
+                sel = np.unique(np.linspace(0, r1 - r0 - 1, 48).astype(np.int64))
+                eng.gen_queries(r1 - r0, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, first_row=r0)
+                qs = np.concatenate([eng.download_queries(int(i), 1) for i in sel])
+                want = eng.query(qs, 1.0, want_dists=False)
+                got = recv[r].cpu().numpy().view(np.uint32)[sel]
+                assert np.array_equal(got, want), f"fixed-Q leg: rank {r}'s gathered ids differ from rank 0's recomputation"
+                checked += len(sel)
+            out["fixed_q"] = {"query_set": QSET, "scaling": "strong", "value": QSET / fq_s, "unit": "queries/s", "ms": fq_s * 1e3,
+                              "rccl_ranks": dist.get_world_size(), "gathered_bytes": (world - 1) * max_share * K * 4,
+                              "rank_ms_min": local_min * 1e3, "rank_ms_max": local_max * 1e3,
+                              "scope": "every rank: its share of the 4x10^6-query set from pageable host memory -> HBM -> one resident "
+                                       "call -> RCCL gather of the ids to rank 0's HBM (timed region ends there)",
+                              "rank0_device_ms": tm.query_ms, "sampled_queries_checked_on_rank0": checked}
+        del q_host, send, recv
+
     # ---- CPU baseline + recall leg (rank 0, N=1 only; the oracle is the checker, never the product)
     if rank == 0 and world == 1 and a.cpu_seconds > 0 and min(a.cpu_queries, a.batch) > 0:
         nodes = eng.download_data(0, a.n)
@@ -375,6 +459,55 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and not a.no_configs12:
         out["configs12"] = configs12_leg(pkg, T, np)
+    # ---- in-library leg (--in-library; rank 0 after every rank has released its GPU): ONE context over all GPUs
+    # (hvs_create_multi: what the vec_query seam and hvs_search.out use), one hvs_query of the whole 4x10^6-query set from
+    # host memory to host memory -- the same job as the process-per-GPU fixed-Q leg, through the seam's own path.
+    if a.in_library or world > 1:
+        # (host-side rendezvous through the process group's store: a collective barrier would leave a spinning RCCL kernel on
+        # every GPU the in-library context is about to use)
+        store = dist.distributed_c10d._get_default_store() if use_dist else None
+        if use_dist:
+            torch.cuda.synchronize()
+            store.add("hvs_inlib_arrived", 1)
+            if rank == 0:
+                import datetime
+                t_wait = time.time()
+                while int(store.add("hvs_inlib_arrived", 0)) < world and time.time() - t_wait < 300:
+                    time.sleep(0.05)
+        if rank == 0:
+            try:
+                QSET = 4_000_000
+                ngpu = max(world, 1) if not a.in_library_devices else len(a.in_library_devices.split(","))
+                devs = [int(x) for x in a.in_library_devices.split(",")] if a.in_library_devices else list(range(ngpu))
+                ids_all = np.empty((QSET, K), np.uint32)
+                with pkg.Engine(devices=devs) as m:
+                    m.reserve(QSET)
+                    m.gen_data(a.n, T.SEED_DATA, a.profile, 100)
+                    m.gen_queries(QSET, T.SEED_QUERY, T.GEN_V1, 100, a.force_type, 0)
+                    q_all = m.download_queries(0, QSET)                   # the query file, in (pageable) host memory
+                    m.query(q_all[:65536 * len(devs)], 1.0, want_dists=False)
+                    t1 = time.perf_counter()
+                    m.query(q_all, 1.0, want_dists=False, out_ids=ids_all)
+                    lib_s = time.perf_counter() - t1
+                    tm = m.last_timing()
+                sel = np.unique(np.linspace(0, QSET - 1, 64 * len(devs)).astype(np.int64))
+                with pkg.Engine(devs[0]) as e1:
+                    e1.gen_data(a.n, T.SEED_DATA, a.profile, 100)
+                    want = e1.query(q_all[sel], 1.0, want_dists=False)
+                assert np.array_equal(ids_all[sel], want), "in-library leg: ids differ from a one-GPU recomputation"
+                out["in_library"] = {"value": QSET / lib_s, "unit": "queries/s", "ms": lib_s * 1e3, "devices": devs, "n_gpus": int(tm.n_gpus),
+                                     "slowest_gpu_device_ms": tm.query_ms, "sampled_queries_checked": int(len(sel)),
+                                     "scope": "one hvs_create_on_devices context, one hvs_query of 4x10^6 queries, pageable host memory -> "
+                                              "pageable host memory (each GPU's pipeline writes its slice of the caller's array)"}
+            except Exception as ex:                                       # the leg must never cost the bench line
+                out["in_library"] = {"error": repr(ex)[:300]}
+        if use_dist:
+            import datetime
+            if rank == 0:
+                store.set("hvs_inlib_done", "1")
+            else:
+                store.wait(["hvs_inlib_done"], datetime.timedelta(seconds=900))
+
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -31,9 +31,54 @@ thread_local std::string g_global_err;
 
 }  // namespace
 
-struct hvs_ctx {
-    int device = 0;
+// Workspace of ONE query batch and the stream it runs on -- a "lane".  A context owns two (round 4): the last level of batch b
+// ends with its re-scoring (HBM-bound gathers) and the final merge (latency-bound), both of which leave the matrix pipes idle,
+// and batch b+1 begins with preparation, the exact seed and two small filter levels that cannot fill the chip; with batch
+// b+1 on the other lane's stream the two ends run side by side.  hvs_ctx IS its main lane (base class: every `c->fb`,
+// `c->stream` ... below means "the lane this batch runs on"); run_queries swaps the spare lane in for every other batch.
+struct HvsLane {
     hipStream_t stream = nullptr;
+    // sort of the batch's queries
+    uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
+    uint32_t *d_qidx = nullptr, *d_qorder = nullptr;
+    uint32_t *d_qra = nullptr, *d_qrb = nullptr;  // position range of each query of the batch, by batch-local index
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t batch_cap = 0;
+    // exact engine: per-(query, chunk) candidate lists
+    uint64_t* d_cand = nullptr;
+    uint32_t* d_cand_cnt = nullptr;
+    size_t cand_lists = 0;
+    // filter engines: per-slot / per-group state
+    HvsBatch fb{};
+    uint32_t fb_slots_cap = 0;
+    size_t fb_cand_entries = 0, fb_pair_entries = 0;  // capacity of fb.cand / fb.pairs in entries
+    uint32_t* d_layout = nullptr;
+    // work-item lists of the current batch (HvsItems): per-quad block ranges, per-segment counts / offsets, the list
+    uint32_t *d_qlo = nullptr, *d_qhi = nullptr, *d_segcnt = nullptr, *d_segoff = nullptr, *d_lvloff = nullptr, *d_cursor = nullptr;
+    uint32_t* d_items = nullptr;
+    size_t items_cap = 0;
+    uint32_t quads_cap = 0, segs_cap = 0;
+    HvsSegs segs{};  // of the current batch
+    uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
+};
+
+struct hvs_ctx : HvsLane {
+    int device = 0;
+    HvsLane spare;                 // the second lane (its buffers are allocated by the first call that has two batches)
+    bool lanes_failed = false;     // no room for a second workspace: calls stay on one lane
+    hipEvent_t ev_lane = nullptr;  // end of the spare lane's latest batch
+    // end of the LAST level's filter launch of the latest batch on the main / the spare lane: the next batch (other lane) starts
+    // behind it -- its head then runs beside this batch's last re-scoring and final merge, not beside its filter launches (two
+    // crews of filter workgroups streaming different tiles through the same L2s: measured 12 % slower than one lane)
+    hipEvent_t ev_fdone[2] = {nullptr, nullptr};
+    hipEvent_t ev_fdone_cur = nullptr;  // the one the batch being enqueued records (nullptr: none)
+    // likewise the end of the filter launch of the level BEFORE the last: the next batch's preparation (query sort, slot layout,
+    // fragments, work-item lists -- memory- and latency-bound) starts behind it and runs beside this batch's re-scoring of
+    // that level; its compute-heavy part (exact seed, low filter levels) waits for ev_fdone (`gate_heavy`)
+    hipEvent_t ev_pdone[2] = {nullptr, nullptr};
+    hipEvent_t ev_pdone_cur = nullptr;
+    hipEvent_t gate_heavy = nullptr;    // what the batch being enqueued waits for between its preparation and its seed
     int engine = HVS_ENGINE_AUTO;
     bool scalar_order = false;  // baseline engine's summation order (exact engine only)
     uint32_t k = HVS_KNN;       // neighbours per query (hvs_set_k; the reference's KNN_LIMIT, optimized_impl.h:26)
@@ -53,16 +98,6 @@ struct hvs_ctx {
     float* d_out_dists = nullptr;
     uint32_t res_cap = 0;
 
-    // workspace of one query batch
-    uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
-    uint32_t *d_qidx = nullptr, *d_qorder = nullptr;
-    uint32_t *d_qra = nullptr, *d_qrb = nullptr;  // position range of each query of the batch, by batch-local index
-    void* d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    uint32_t batch_cap = 0;
-    uint64_t* d_cand = nullptr;
-    uint32_t* d_cand_cnt = nullptr;
-    size_t cand_lists = 0;
     unsigned long long* d_counters = nullptr;
 
     // ---- MFMA engine: index over D (two orderings) ...
@@ -82,17 +117,7 @@ struct hvs_ctx {
     bool f16_rejected = false; // likewise the FP16 tiles (components beyond the half-precision range)
     double index_ms = 0.0;
     bool index_too_large = false;  // more than 2^27 rows: no filter index (hvs_timing.flags says so)
-    // ... and per-batch state
-    HvsBatch fb{};
-    uint32_t fb_slots_cap = 0;
-    size_t fb_cand_entries = 0, fb_pair_entries = 0;  // capacity of fb.cand / fb.pairs in entries
-    uint32_t* d_layout = nullptr;
-    // work-item lists of the current batch (HvsItems): per-quad block ranges, per-segment counts / offsets, the list
-    uint32_t *d_qlo = nullptr, *d_qhi = nullptr, *d_segcnt = nullptr, *d_segoff = nullptr, *d_lvloff = nullptr, *d_cursor = nullptr;
-    uint32_t* d_items = nullptr;
-    size_t items_cap = 0;
-    uint32_t quads_cap = 0, segs_cap = 0;
-    HvsSegs segs{};  // of the current batch
+    // (the per-batch state of the filter engines lives in the lanes)
     int num_cus = 256;
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;      // queries for the exact engine; d_ovf_count[0..1] = exact, retry
     uint32_t* d_retry_list = nullptr;                            // queries whose guessed threshold was not verified
@@ -102,8 +127,6 @@ struct hvs_ctx {
     HvsGuessTable guess_tab[13]{};  // order statistics of the guessed thresholds for k = guess_k: [0] proven (retry batches),
     bool guess_have[13] = {};       // [p] failure target 10^-p
     uint32_t guess_k = 0;
-
-    uint32_t class_counts[5] = {0, 0, 0, 0, 0};  // queries per predicate class in the current batch
 
     hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;
     // start/stop event pairs around the dominant kernel's launches of the current call (grown on demand: a call
@@ -213,6 +236,30 @@ const uint32_t kGuessPfail = env_u32("HVS_GUESS_PFAIL", 0u, 0u, 12u);
 uint32_t guess_pfail_for(uint32_t nqb) { return kGuessPfail ? kGuessPfail : (nqb >= (1u << 18) ? 3u : (nqb >= (1u << 15) ? 4u : 6u)); }
 constexpr uint32_t kMfmaMinRows = 32768;  // below this the exact engine is used by HVS_ENGINE_AUTO
 constexpr uint32_t kIndexMinRows = 4096;  // below this no index is built (the exact engine scans all rows)
+
+// two lanes (see HvsLane): HVS_LANES=0 keeps every batch on the main lane (A/B runs)
+const bool kLanes = env_u32("HVS_LANES", 1u, 0u, 1u) != 0u;
+void swap_lanes(hvs_ctx* c) { std::swap(static_cast<HvsLane&>(*c), c->spare); }
+struct LaneGuard {  // the spare lane is swapped in for the duration of one batch, whatever way the batch ends
+    hvs_ctx* c;
+    bool on;
+    ~LaneGuard()
+    {
+        if (on) swap_lanes(c);
+    }
+};
+void free_lane(HvsLane& L)
+{
+    HvsBatch& B = L.fb;
+    void* ptrs[] = {L.d_keys, L.d_keys_sorted, L.d_qidx, L.d_qorder, L.d_qra, L.d_qrb, L.d_sort_tmp, L.d_cand, L.d_cand_cnt,
+                    B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
+                    B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
+                    L.d_layout, L.d_qlo, L.d_qhi, L.d_segcnt, L.d_segoff, L.d_lvloff, L.d_cursor, L.d_items};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+    L = HvsLane{};
+}
 
 // HVS_TRACE=1: hvs_query prints the host-side phases of a call (microseconds since its start) to stderr -- where a small
 // call's wall time goes between the caller's buffers and the first / last kernel
@@ -902,7 +949,7 @@ int prep_batch(hvs_ctx* c, uint32_t q0, uint32_t nqb, bool count_pairs, int fmt,
     size_t tmp = c->sort_tmp_bytes;
     HVS_HIP(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys_sorted, c->d_qidx, c->d_qorder,
                                          (size_t)nqb, 0, 64, c->stream));
-    hipLaunchKernelGGL(hvs_k_layout, dim3(1), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, q0, list,
+    hipLaunchKernelGGL(hvs_k_layout, dim3(std::min(hvs_ceil_div(B.nslots, 1024u), 1024u)), dim3(1024), 0, c->stream, c->d_keys_sorted, c->d_qorder, nqb, B.nslots, q0, list,
                        c->d_qra, c->d_qrb, B.qid, B.rank, B.ra, B.rb, c->d_layout);
     // (last argument: the batch is for a filter engine -- `host_counts` is the exact engine's range scan, which answers every
     // query itself, non-finite ones included)
@@ -975,7 +1022,8 @@ int run_batch_exact_ranges(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn)
 }
 
 // work-item lists of the batch just prepared (all levels at once; see HvsItems in hvs_filter.h)
-int build_items(hvs_ctx* c)
+// buffers of the work-item lists for the batch whose slot layout ensure_filter_workspace has just set (c->fb.ngroups)
+int ensure_items(hvs_ctx* c)
 {
     const HvsBatch& B = c->fb;
     const HvsLevels L = c->lv;
@@ -987,11 +1035,13 @@ int build_items(hvs_ctx* c)
     if (nquads > (1u << HVS_ITEM_QUAD_BITS)) return fail(c, HVS_EINVAL, "internal: too many query quads for the item code");
     int rc;
     if (nquads > c->quads_cap) {
+        c->quads_cap = 0;
         if ((rc = dev_alloc(c, &c->d_qlo, (size_t)nquads))) return rc;
         if ((rc = dev_alloc(c, &c->d_qhi, (size_t)nquads))) return rc;
         c->quads_cap = nquads;
     }
     if (nseg + 1u > c->segs_cap) {
+        c->segs_cap = 0;
         if ((rc = dev_alloc(c, &c->d_segcnt, (size_t)nseg + 1u))) return rc;
         if ((rc = dev_alloc(c, &c->d_segoff, (size_t)nseg + 1u))) return rc;
         c->segs_cap = nseg + 1u;
@@ -1000,9 +1050,22 @@ int build_items(hvs_ctx* c)
     if (!c->d_cursor && (rc = dev_alloc(c, &c->d_cursor, (size_t)16))) return rc;
     const size_t worst = (size_t)nquads * (size_t)(nseg - S.first[1]);  // every quad meets every segment (type 0)
     if (worst > c->items_cap) {
+        c->items_cap = 0;
         if ((rc = dev_alloc(c, &c->d_items, worst))) return rc;
         c->items_cap = worst;
     }
+    return HVS_OK;
+}
+
+int build_items(hvs_ctx* c)
+{
+    int rc = ensure_items(c);
+    if (rc) return rc;
+    const HvsBatch& B = c->fb;
+    const HvsLevels L = c->lv;
+    const uint32_t nquads = hvs_ceil_div(B.ngroups, HVS_WG_WAVES);
+    const HvsSegs S = c->segs;
+    const uint32_t nseg = S.first[L.K + 1];
     HVS_HIP(c, hipMemsetAsync(c->d_cursor, 0, 16 * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(hvs_k_quad_ranges, dim3(hvs_ceil_div(nquads, 256u)), dim3(256), 0, c->stream, B, nquads, c->d_qlo, c->d_qhi);
     hipLaunchKernelGGL(hvs_k_item_sweep<false>, dim3(nseg), dim3(256), 0, c->stream, L, S, nquads, c->d_qlo, c->d_qhi, c->d_segcnt,
@@ -1094,6 +1157,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
         hipLaunchKernelGGL(hvs_k_count_prefix_pairs, dim3(B.nslots), dim3(64), 0, c->stream, B, c->d_perm_ct, c->d_perm_t, sn,
                            c->d_counters);
 
+    if (c->gate_heavy) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->gate_heavy, 0));  // (two lanes: see hvs_ctx::ev_pdone)
     // level 0 by the exact kernel; small batches cut it into chunks so that enough waves are in flight
     const uint32_t l0blocks = L.off[1] - L.off[0];
     const uint32_t seed_waves = hvs_ceil_div(B.nslots, 64u);
@@ -1147,6 +1211,8 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
                 hipLaunchKernelGGL(hvs_k_filter_mfma<HVS_FMT_BF16>, fgrid, dim3(64 * HVS_WG_WAVES), 0, c->stream, c->d_tiles_ct,
                                    c->d_tiles_t, c->d_nrm_ct, c->d_nrm_t, c->d_bpos_ct, c->d_bpos_t, L, level, B, W, c->d_counters);
             kernel_timer_end(c, ev);
+            if (level == L.K && c->ev_fdone_cur) HVS_HIP(c, hipEventRecord(c->ev_fdone_cur, c->stream));
+            if (level + 1u == L.K && c->ev_pdone_cur) HVS_HIP(c, hipEventRecord(c->ev_pdone_cur, c->stream));
         }
         if (fmt == HVS_FMT_I8X16)
             hipLaunchKernelGGL(hvs_k_rescore<true>, dim3(rescore_blocks, B.ngroups), dim3(64 * HVS_RESCORE_WAVES), 0, c->stream, c->d_data, n,
@@ -1374,17 +1440,55 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     const bool ranges = !mfma && c->have_index;  // exact engine: scan position ranges when the index exists
     const std::vector<uint32_t> sched = batch_schedule(nq, mfma ? kBatchMfma : kBatch, host_pipeline && mfma);
+    // Two lanes (HvsLane): every other batch of a filter-engine call runs on the spare lane's stream and workspace, so that
+    // its preparation, seed and low levels share the chip with the previous batch's last re-scoring and final merge.  The
+    // spare lane starts behind the call's counter resets (ev_q0) and the main stream joins it before the call ends.
+    bool two_lanes = mfma && kLanes && sched.size() >= 2 && !c->lanes_failed;
+    bool spare_used = false;
     uint32_t off = 0;
     for (size_t b = 0; b < sched.size(); ++b) {
         const uint32_t nqb = sched[b];
+        LaneGuard lane{c, false};
+        if (two_lanes && (b & 1u)) {
+            swap_lanes(c);
+            lane.on = true;
+            // the spare workspace is allocated here, ahead of the batch: without room for it the call stays on one lane
+            int rcw = ensure_filter_workspace(c, nqb);
+            if (!rcw) rcw = ensure_items(c);
+            if (rcw == HVS_ENOMEM) {
+                (void)hipGetLastError();
+                c->err.clear();
+                swap_lanes(c);
+                lane.on = false;
+                two_lanes = false;
+                c->lanes_failed = true;
+            } else if (rcw) {
+                return rcw;
+            } else if (!spare_used) {
+                HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_q0, 0));
+                spare_used = true;
+            }
+        }
+        if (two_lanes) {
+            // this batch's preparation starts behind the previous batch's (other lane) second-to-last filter launch, its seed
+            // behind the last one; it records its own two events
+            const bool have_prev = b > 0 && c->lv.K >= 1u;
+            if (have_prev) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->lv.K >= 2u ? c->ev_pdone[(b - 1u) & 1u] : c->ev_fdone[(b - 1u) & 1u], 0));
+            c->gate_heavy = have_prev ? c->ev_fdone[(b - 1u) & 1u] : nullptr;
+            c->ev_fdone_cur = c->ev_fdone[b & 1u];
+            c->ev_pdone_cur = c->ev_pdone[b & 1u];
+        }
         int rc = hooks.before(off, nqb);
-        if (rc) return rc;
-        rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn, nullptr, false)
-                  : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
+        if (!rc)
+            rc = mfma ? run_batch_mfma(c, q0 + off, nqb, sn, nullptr, false)
+                      : (ranges ? run_batch_exact_ranges(c, q0 + off, nqb, sn) : run_batch_exact(c, q0 + off, nqb, sn));
+        c->ev_fdone_cur = c->ev_pdone_cur = c->gate_heavy = nullptr;
         if (rc) return rc;
         if ((rc = hooks.after(off, nqb, b + 1 < sched.size() ? sched[b + 1] : 0u))) return rc;
+        if (lane.on) HVS_HIP(c, hipEventRecord(c->ev_lane, c->stream));
         off += nqb;
     }
+    if (spare_used) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_lane, 0));
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
     if (mfma) {
         HVS_HIP(c, hipMemcpyAsync(c->h_ovf, c->d_ovf_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1444,6 +1548,12 @@ int leaf_create(hvs_ctx** out, int device)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->spare.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_lane, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (hipEvent_t& ev : c->ev_fdone)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (hipEvent_t& ev : c->ev_pdone)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev_q0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1471,21 +1581,19 @@ void leaf_destroy(hvs_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->s_in) (void)hipStreamSynchronize(c->s_in);
     if (c->s_out) (void)hipStreamSynchronize(c->s_out);
-    void* ptrs[] = {c->d_data, c->d_q,      c->d_out_ids,  c->d_out_dists, c->d_keys,     c->d_keys_sorted,
-                    c->d_qidx, c->d_qorder, c->d_sort_tmp, c->d_cand,      c->d_cand_cnt, c->d_counters,
-                    c->d_qra,  c->d_qrb};
+    if (c->spare.stream) (void)hipStreamSynchronize(c->spare.stream);
+    void* ptrs[] = {c->d_data, c->d_q, c->d_out_ids, c->d_out_dists, c->d_counters, c->d_bounds, c->d_quant,
+                    c->d_ovf_list, c->d_ovf_count, c->d_retry_list, c->d_demote_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     free_index(c);
-    {
-        HvsBatch& B = c->fb;
-        void* fp[] = {B.qid, B.rank, B.ra, B.rb, B.gua, B.gub, B.gord, B.bfrag, B.theta, B.qn, B.normq, B.eq, B.nqb,
-                      B.top, B.topcnt, B.tau, B.cand, B.candcnt, B.overflow, B.pairs, B.paircnt, B.goverflow,
-                      c->d_bounds, c->d_quant, c->d_layout, c->d_ovf_list, c->d_ovf_count, c->d_retry_list, c->d_demote_list,
-                      c->d_qlo, c->d_qhi, c->d_segcnt, c->d_segoff, c->d_lvloff, c->d_cursor, c->d_items};
-        for (void* p : fp)
-            if (p) (void)hipFree(p);
-    }
+    free_lane(c->spare);
+    free_lane(static_cast<HvsLane&>(*c));
+    if (c->ev_lane) (void)hipEventDestroy(c->ev_lane);
+    for (hipEvent_t ev : c->ev_fdone)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->ev_pdone)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     for (int i = 0; i < hvs_ctx::kRing; ++i) {
         if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
@@ -1499,7 +1607,6 @@ void leaf_destroy(hvs_ctx* c)
     if (c->ev_q0) (void)hipEventDestroy(c->ev_q0);
     if (c->ev_q1) (void)hipEventDestroy(c->ev_q1);
     for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
 }
@@ -1522,7 +1629,23 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     const bool filter_runs = c->have_index && (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
                                                c->engine == HVS_ENGINE_MFMA_F16 ||
                                                (c->engine == HVS_ENGINE_AUTO && c->n >= kMfmaMinRows && c->planned_fmt != HVS_FMT_NONE));
-    if (filter_runs) return ensure_filter_workspace(c, std::min(nq, kBatchMfma));
+    if (filter_runs) {
+        if ((rc = ensure_filter_workspace(c, std::min(nq, kBatchMfma)))) return rc;
+        if ((rc = ensure_items(c))) return rc;
+        if (kLanes && nq > kBatchMfma && !c->lanes_failed) {  // calls of two batches and more alternate between two lanes
+            LaneGuard lane{c, true};
+            swap_lanes(c);
+            rc = ensure_filter_workspace(c, std::min(nq - kBatchMfma, kBatchMfma));
+            if (!rc) rc = ensure_items(c);
+            if (rc == HVS_ENOMEM) {
+                (void)hipGetLastError();
+                c->err.clear();
+                c->lanes_failed = true;
+                rc = HVS_OK;
+            }
+        }
+        return rc;
+    }
     if (c->have_index) return ensure_filter_workspace(c, std::min(nq, kBatch));
     const uint32_t nqb = std::min(nq, kBatch);
     return ensure_batch_workspace(c, nqb, make_plan(nqb, c->n ? c->n : 1u));
@@ -1875,13 +1998,17 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
     // everything BEFORE batch b are sent out and drained, and the copy-out stream is told to wait for batch b.  The
     // host work of a batch (two staging copies, ~0.2 s per 2^20 queries) hides under the batch's own compute.
     uint32_t staged_q = 0;  // queries [0, staged_q) are enqueued on the copy-in stream and the compute stream waits for them
-    auto send_input = [&](uint32_t upto_q) -> int {
+    auto send_input = [&](uint32_t upto_q, bool wait_here) -> int {
         upto_q = std::min(nq, upto_q);
-        if (upto_q <= staged_q) return HVS_OK;
+        if (upto_q <= staged_q) {
+            // staged by the previous batch's hook, which made ITS lane's stream wait: this batch's stream waits itself
+            if (wait_here && staged_q) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
+            return HVS_OK;
+        }
         int r2 = stage_in_until(std::min(npieces, hvs_ceil_div(upto_q, SQ)));
         if (r2) return r2;
         HVS_HIP(c, hipEventRecord(c->ev_stage, c->s_in));
-        HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
+        if (wait_here) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
         staged_q = std::min(nq, in_next * SQ);
         return HVS_OK;
     };
@@ -1890,11 +2017,11 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         decltype(copy_out_until)& copy_out;
         hvs_ctx* c;
         uint32_t nq;
-        int before(uint32_t off, uint32_t nqb) const { return send(off + nqb); }
+        int before(uint32_t off, uint32_t nqb) const { return send(off + nqb, true); }
         int after(uint32_t off, uint32_t nqb, uint32_t next_nqb) const
         {
             int r2;
-            if (next_nqb && (r2 = send(off + nqb + next_nqb))) return r2;
+            if (next_nqb && (r2 = send(off + nqb + next_nqb, false))) return r2;
             if ((r2 = copy_out(off / hvs_ctx::kStageQ))) return r2;  // whole pieces of the batches before this one
             HVS_HIP(c, hipEventRecord(c->ev_batch, c->stream));
             HVS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_batch, 0));

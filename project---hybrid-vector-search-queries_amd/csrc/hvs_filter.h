@@ -838,14 +838,17 @@ __global__ void hvs_k_query_keys2(const float* __restrict__ Q, uint32_t q0, uint
 }
 
 // Slot layout: each class padded to whole 32-slot blocks, the (C,T) part padded to a whole quad of
-// groups (a filter workgroup serves one quad and one ordering), the type-2 part to a whole group.  One thread block; writes the slot -> query map.
+// groups (a filter workgroup serves one quad and one ordering), the type-2 part to a whole group.  Writes the slot -> query map.
 // layout[0..4] = first slot of each class rank, layout[5] = nslots used, layout[6] = first group of T part
-// `sorted_idx` holds batch-local indices i: the query is list[i] (retry batches) or q0 + i, its position range qa[i], qb[i]
-__global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
-                             uint32_t nq, uint32_t nslots_cap, uint32_t q0, const uint32_t* __restrict__ list,
-                             const uint32_t* __restrict__ qa, const uint32_t* __restrict__ qb, uint32_t* __restrict__ qid,
-                             uint32_t* __restrict__ rank, uint32_t* __restrict__ ra, uint32_t* __restrict__ rb,
-                             uint32_t* __restrict__ layout)
+// `sorted_idx` holds batch-local indices i: the query is list[i] (retry batches) or q0 + i, its position range qa[i], qb[i].
+// Any number of 1024-thread blocks (round 4: ONE block walked all 2^21 slots of a full batch -- 4 ms alone, 14 ms beside the
+// previous batch's re-scoring on the other lane): every block derives the class boundaries itself (six binary searches) and
+// takes its own 1024 slots; block 0 writes `layout`.
+__global__ __launch_bounds__(1024) void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
+                                                     uint32_t nq, uint32_t nslots_cap, uint32_t q0, const uint32_t* __restrict__ list,
+                                                     const uint32_t* __restrict__ qa, const uint32_t* __restrict__ qb,
+                                                     uint32_t* __restrict__ qid, uint32_t* __restrict__ rank, uint32_t* __restrict__ ra,
+                                                     uint32_t* __restrict__ rb, uint32_t* __restrict__ layout)
 {
     __shared__ uint32_t first[6];   // first sorted index of each rank (first[5] = nq)
     __shared__ uint32_t slot0[6];
@@ -868,12 +871,14 @@ __global__ void hvs_k_layout(const uint64_t* __restrict__ sorted_keys, const uin
             s += hvs_ceil_div(cnt, 32u) * 32u;
         }
         slot0[5] = hvs_ceil_div(s, HVS_GROUP) * HVS_GROUP;
-        for (uint32_t rk = 0; rk < 5u; ++rk) layout[rk] = slot0[rk];
-        layout[5] = slot0[5];
-        layout[6] = slot0[4] / HVS_GROUP;
+        if (blockIdx.x == 0u) {
+            for (uint32_t rk = 0; rk < 5u; ++rk) layout[rk] = slot0[rk];
+            layout[5] = slot0[5];
+            layout[6] = slot0[4] / HVS_GROUP;
+        }
     }
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < nslots_cap; s += blockDim.x) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nslots_cap; s += gridDim.x * blockDim.x) {
         uint32_t rk = 0;
         while (rk < 4u && s >= slot0[rk + 1]) ++rk;
         const uint32_t off = s - slot0[rk];
