@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--profile", type=int, default=1,
                     help="vector law of D and Q (include/hvs_gen.h): 1 gen-v1 uniform (the headline), 2 clustered, 3 PCA-like "
                          "decaying variances, 4 heavy-tailed norms, 5 gen-v1; 2-5: 1 %% of the queries lie outside the data's box")
-    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+    ap.add_argument("--cpu-seconds", type=float, default=150.0,
                     help="time cap of the CPU baseline leg (0 = skip): it times the fixed --cpu-queries prefix in chunks "
                          "of 256 queries and stops at the first chunk boundary past the cap")
     ap.add_argument("--cpu-queries", type=int, default=2048, help="CPU baseline sample: first N queries of the first timed batch (SURVEY 8d)")
@@ -432,20 +432,52 @@ def main():
         hw = os.cpu_count() or 1
         m_fixed = min(a.cpu_queries, a.batch)
         q = first_timed_q[:m_fixed]
+        rule_threads = max(1, min(hw, a.n // 100000))                   # the reference's own rule, optimized_parallel.hpp:76-77
+        T.oracle().hvs_oracle_pin_threads(1)                            # baseline threads on CPUs of their own for the leg's duration
+        # D placed for the scan: every thread's partition first touched by that thread (the reference reads D on its main
+        # thread, i.e. onto one memory node of a two-socket host; see hvs_oracle_place_rows).  Thread-count mini-sweep on the
+        # first 256 queries (placement redone per thread count): the reference's rule picks min(hw, n / 100000) threads, whose
+        # per-query fork/join (threading.hpp:72-96) can cost more than the extra threads bring -- the timed sample below runs
+        # with the best count of the sweep, the rule's own rate is reported beside it.
+        msweep = min(256, m_fixed)
+        sweep, best_t = {}, rule_threads
+        for tcount in sorted({8, 32, 64, rule_threads}):
+            if tcount > hw:
+                continue
+            pl, _ = T.oracle_place_rows(nodes, 1.0, tcount, hw)
+            t1 = time.perf_counter()
+            T.oracle_query(pl, q[:msweep], engine="knn", part_threads=tcount, hw_threads=hw, run_parallel=True)
+            sweep[str(tcount)] = msweep / (time.perf_counter() - t1)
+            del pl
+        best_t = int(max(sweep, key=lambda k: sweep[k]))
+        # the rule's thread count on the UNPLACED array (everything on the node the download thread ran on), for the record
+        t1 = time.perf_counter()
+        T.oracle_query(nodes, q[:msweep], engine="knn", part_threads=0, hw_threads=hw, run_parallel=True)
+        unplaced = msweep / (time.perf_counter() - t1)
+        placed, _ = T.oracle_place_rows(nodes, 1.0, best_t, hw)
         ref_parts, done, cpu_s = [], 0, 0.0
         while done < m_fixed and cpu_s < a.cpu_seconds:                  # fixed prefix, in chunks of 256, capped in time
             m = min(256, m_fixed - done)
             t1 = time.perf_counter()
-            r_ids, _ = T.oracle_query(nodes, q[done:done + m], engine="knn", part_threads=0, hw_threads=hw, run_parallel=True)
+            r_ids, _ = T.oracle_query(placed, q[done:done + m], engine="knn", part_threads=best_t, hw_threads=hw, run_parallel=True)
             cpu_s += time.perf_counter() - t1
             ref_parts.append(r_ids)
             done += m
+        T.oracle().hvs_oracle_pin_threads(0)
         ref_ids = np.concatenate(ref_parts)
-        threads = max(1, min(hw, a.n // 100000))                        # optimized_parallel.hpp:76-77
-        out["cpu_baseline"] = {"value": done / cpu_s, "unit": "queries/s", "cores": threads, "kind": "port",
+        mq = T.passing_rows_per_query(nodes, q[:done])
+        row_bytes = float(np.sum(8.0 * a.n + 400.0 * mq))               # attributes of every row + vectors of passing rows
+        out["cpu_baseline"] = {"value": done / cpu_s, "unit": "queries/s", "cores": best_t, "threads": best_t, "kind": "port",
+                               "row_data_gb_per_s": row_bytes / cpu_s / 1e9,
+                               "reference_rule_threads": rule_threads,
+                               "threads_sweep_queries_per_s_on_256_queries": sweep,
+                               "reference_rule_threads_without_numa_placement_queries_per_s": unplaced,
                                "sample": f"first {done} queries of the fixed {m_fixed}-query prefix of the first timed batch "
                                          f"(SURVEY 8d; chunks of 256 until {a.cpu_seconds:.0f} s), full D={a.n}; "
-                                         f"reference-faithful D-partitioned Knn engine (oracle), host has {hw} cpus"}
+                                         f"reference-faithful D-partitioned Knn engine (oracle: optimized_parallel.hpp:91-160, "
+                                         f"threading.hpp:116-118) on the best thread count of the sweep, threads pinned, D first-touched "
+                                         f"per partition; host has {hw} cpus"}
+        del placed
         got, got_d = first_timed_ids[:done], first_timed_dists[:done]
         can_ids, _ = T.oracle_query(nodes, q[:done], engine="canonical", threads=hw)
         st = T.check_parity(nodes, q[:done], got, can_ids, got_dists=got_d)

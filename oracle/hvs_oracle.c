@@ -1,3 +1,6 @@
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sched_setaffinity: the timed CPU baseline pins its threads */
+#endif
 /*
  * hvs_oracle.c -- CPU restatement of the reference's filtered brute-force k-NN path.
  *
@@ -18,13 +21,76 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#ifdef __linux__
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
+#endif
 #endif
 
 #include "../include/hvs_gen.h"
+
+/* Thread t of T on a CPU of its own, spread evenly over the CPUs this process may use, for the duration of a parallel region of
+ * the timed baseline (the partition a thread first touches is then the one it scans, on the same memory node).  The calling
+ * thread (t = 0) gets its old mask back from pin_restore: threads it starts later must not inherit a one-CPU mask. */
+#ifdef __linux__
+static int g_pin_threads = 0; /* hvs_oracle_pin_threads */
+static void pin_self(uint32_t t, uint32_t T, cpu_set_t *saved)
+{
+    if (!g_pin_threads) return;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    if (saved) *saved = allowed;
+    /* one hardware thread per core first (the lowest-numbered CPU of each thread_siblings_list), the SMT siblings behind them:
+     * T <= cores threads are spread evenly over the cores (and thereby over the sockets), more threads fill the siblings */
+    static int order[CPU_SETSIZE], nprim = -1, nall = 0;
+#pragma omp critical(hvs_pin_topology)
+    if (nprim < 0) {
+        int prim[CPU_SETSIZE], sec[CPU_SETSIZE], np = 0, ns = 0;
+        for (int c = 0; c < CPU_SETSIZE; ++c) {
+            if (!CPU_ISSET(c, &allowed)) continue;
+            char path[128];
+            int first = c;
+            snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            FILE *f = fopen(path, "r");
+            if (f) {
+                if (fscanf(f, "%d", &first) != 1) first = c;
+                fclose(f);
+            }
+            if (first == c) prim[np++] = c; else sec[ns++] = c;
+        }
+        for (int i = 0; i < np; ++i) order[i] = prim[i];
+        for (int i = 0; i < ns; ++i) order[np + i] = sec[i];
+        nall = np + ns;
+        nprim = np;
+    }
+    if (nall < (int)T) return; /* fewer CPUs than threads: leave it to the scheduler */
+    const int cpu = (int)T <= nprim ? order[(size_t)t * (size_t)nprim / T] : order[t];
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    (void)sched_setaffinity(0, sizeof(one), &one);
+}
+static void pin_restore(const cpu_set_t *saved)
+{
+    if (g_pin_threads) (void)sched_setaffinity(0, sizeof(*saved), saved);
+}
+#endif
+void hvs_oracle_pin_threads(int on)
+{
+#ifdef __linux__
+    g_pin_threads = on;
+#else
+    (void)on;
+#endif
+}
+
 
 #define DCOLS 102
 #define QCOLS 104
@@ -422,6 +488,11 @@ int hvs_oracle_vec_query_knn(const float *nodes, uint32_t n, const float *querie
 #else
             const uint32_t t = 0;
 #endif
+#ifdef __linux__
+            cpu_set_t saved;
+            CPU_ZERO(&saved);
+            pin_self(t, T, t == 0 ? &saved : NULL);
+#endif
             for (uint32_t i = 0; i < nq; ++i) {
                 const float *q = queries + (size_t)i * QCOLS;
                 const qparams p = parse_query(q);
@@ -441,6 +512,9 @@ int hvs_oracle_vec_query_knn(const float *nodes, uint32_t n, const float *querie
                                out_dists ? out_dists + (size_t)i * KNN : NULL);
                 } /* implicit barrier */
             }
+#ifdef __linux__
+            if (t == 0) pin_restore(&saved);
+#endif
         }
     } else {
         for (uint32_t i = 0; i < nq; ++i) {
@@ -462,6 +536,47 @@ int hvs_oracle_vec_query_knn(const float *nodes, uint32_t n, const float *querie
     }
     free(knns);
     return 0;
+}
+
+/*
+ * Placement of D for the timed CPU baseline on a multi-socket host.  The reference reads D into per-row heap blocks from
+ * its main thread (io.h:111-136), i.e. on ONE memory node, and its workers then scan fixed partitions
+ * (threading.hpp:116-118); on a two-socket GPU host that leaves half of the threads reading remote memory.  To time the
+ * reference's algorithm at its best, thread t of the SAME static partition (and, with OMP_PROC_BIND set, the same core)
+ * copies its rows into `dst` first, so that every partition's pages are first touched -- and therefore placed -- next to
+ * the thread that will scan them.  `dst` must be freshly allocated, untouched memory of n x 102 floats.
+ */
+int hvs_oracle_place_rows(float *dst, const float *src, uint32_t n, float sample_proportion, int part_threads, int hw_threads)
+{
+    const uint32_t sn = hvs_oracle_sn(sample_proportion, n);
+    uint32_t T = (uint32_t)part_threads;
+    if (part_threads <= 0) {
+        uint32_t hw = hw_threads > 0 ? (uint32_t)hw_threads : 1u;
+        uint32_t w = sn / 100000u;
+        T = hw < w ? hw : w;
+        if (T < 1u) T = 1u;
+    }
+    const uint32_t wsize = sn / T;
+#pragma omp parallel num_threads((int)T)
+    {
+#ifdef _OPENMP
+        const uint32_t t = (uint32_t)omp_get_thread_num();
+#else
+        const uint32_t t = 0;
+#endif
+#ifdef __linux__
+        cpu_set_t saved;
+        CPU_ZERO(&saved);
+        pin_self(t, T, t == 0 ? &saved : NULL); /* (worker threads of the OpenMP pool stay where they are put) */
+#endif
+        const size_t start = (size_t)t * wsize;
+        const size_t end = (t == T - 1) ? (size_t)n : start + wsize; /* the last thread also takes rows [sn, n) */
+        memcpy(dst + start * DCOLS, src + start * DCOLS, (end - start) * DCOLS * sizeof(float));
+#ifdef __linux__
+        if (t == 0) pin_restore(&saved);
+#endif
+    }
+    return (int)T;
 }
 
 /* ------------------------------------------------------------------------- *

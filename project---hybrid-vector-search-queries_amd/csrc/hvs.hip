@@ -157,10 +157,16 @@ struct hvs_ctx : HvsLane {
     hipEvent_t ev_batch = nullptr, ev_stage = nullptr;
     uint32_t reserve_nq = 0;  // hvs_reserve: queries per call the caller announced
     uint32_t stage_k = 0;     // k the pinned result slots were sized for
+    bool dma_warm = false;    // the copy engines of s_in / s_out have moved a DMA-sized piece
+    // planner probe (probe_format): the probe batch of 1024 queries stands for the large batches the format will serve, so it
+    // runs with THEIR failure target -- and with their list capacity (HVS_FCAP entries per query and level): a format whose band
+    // overflows that capacity fails in production too
+    uint32_t force_pfail = 0;
 
     // multi-GPU root (hvs_create_multi): owns one leaf context per GPU; D is replicated, the queries of a call are cut
     // into one contiguous range per leaf (optimized_parallel.hpp:91: iterations are independent) and every leaf
     // writes its block of ids straight into its slice of the caller's buffer
+    void* trace = nullptr;  // HVS_TRACE: the HostTrace of the running hvs_load_data
     std::vector<int> node_cpus;  // CPUs of the NUMA node this GPU hangs off (empty: unknown); the leaf's host thread runs there
     std::vector<hvs_ctx*> kids;
     std::vector<uint32_t> kid_q0;  // resident queries: first global index of each leaf's range (kids.size() + 1 entries)
@@ -280,6 +286,11 @@ struct HostTrace {
         if (kTrace) std::fprintf(stderr, "[hvs trace] %s nq=%u:%s\n", tag, nq, line.c_str());
     }
 };
+
+void trace_mark(hvs_ctx* c, const char* what)
+{
+    if (kTrace && c->trace) static_cast<HostTrace*>(c->trace)->mark(what);
+}
 
 int fail(hvs_ctx* c, int code, const std::string& msg)
 {
@@ -629,6 +640,9 @@ int build_tiles(hvs_ctx* c, int fmt)
         // error bound does not model)
         ok = std::isfinite(hb.e_d) && std::isfinite(hb.nb_d) && std::isfinite(hb.hmax) && std::isfinite(hb.rho) &&
              !(hb.hmax > 1.0e30f) && !(hb.hmax > 0.0f && hb.hmax < 1.0e-20f);
+    if (kTrace)
+        std::fprintf(stderr, "[hvs trace] tiles built: format %d usable %d e_d8 %.6g n_d8 %.6g e_d %.6g nb_d %.6g hmax %.6g rho %.6g\n", fmt, (int)ok,
+                     (double)hb.e_d8, (double)hb.n_d8, (double)hb.e_d, (double)hb.nb_d, (double)hb.hmax, (double)hb.rho);
     if (!ok) return HVS_OK;  // have_index stays false
     c->tile_fmt = fmt;
     c->have_index = true;
@@ -712,7 +726,12 @@ int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
     hipLaunchKernelGGL(hvs_k_probe_queries, dim3(hvs_ceil_div(P * HVS_QCOLS, 256u)), dim3(256), 0, c->stream, c->d_data, c->n, step, P, c->d_q);
     hipError_t e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->stream);
+    // (the probe batch is small, but it stands for full batches: their failure target.  Its lists keep the production capacity:
+    // PCA-like vectors at n = 10^7 hand ~1500 rows per type-0 query to the last level's list of 1024 -- INT8 tiles look 23 %
+    // faster than FP16 tiles there only while a half-empty workspace doubles the lists, profiles/r04/nonuniform_int8.txt)
+    c->force_pfail = guess_pfail_for(kBatchMfma);
     int rc = e == hipSuccess ? run_batch_mfma(c, 0, P, c->n, nullptr, false) : fail(c, HVS_EHIP, "planner probe: memset failed");
+    c->force_pfail = 0u;
     unsigned long long h[4] = {0, 0, 0, 0};
     uint32_t fails[2] = {0, 0};
     if (!rc) {
@@ -734,7 +753,7 @@ int probe_format(hvs_ctx* c, double* cost, double* inflation, double* failed)
     // what a filter without any error band would have handed over: m (radix - 1) rows per level under the guessed thresholds
     double ideal = 0.0;
     {
-        const HvsGuessTable G = plan_guess(c->k, false, guess_pfail_for(P));
+        const HvsGuessTable G = plan_guess(c->k, false, guess_pfail_for(kBatchMfma));
         double seen = 1.0;  // fraction of the rows seen, from the last level backwards
         for (uint32_t j = c->lv.K; j >= 1u; --j) {
             seen /= (double)c->lv.radix[j];
@@ -757,6 +776,7 @@ int plan_by_probe(hvs_ctx* c)
     double cost = 0.0, infl = 0.0, failed = 0.0;
     int rc = probe_format(c, &cost, &infl, &failed);
     if (rc) return rc;
+    if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
     int best = c->tile_fmt;
     double best_cost = cost;
     // INT8 tiles stay unless their band visibly lets too much through on this data (the cost formula is not trusted to
@@ -765,6 +785,7 @@ int plan_by_probe(hvs_ctx* c)
         const int had = c->tile_fmt;
         if ((rc = build_tiles_chain(c, HVS_FMT_F16))) return rc;
         if (c->have_index && (rc = probe_format(c, &cost, &infl, &failed))) return rc;
+        if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
         if (c->have_index && cost < best_cost) {
             best = c->tile_fmt;
             best_cost = cost;
@@ -836,15 +857,18 @@ int build_index(hvs_ctx* c)
     ids = nullptr;
     tmp = nullptr;
 #undef HVS_TRY
+    trace_mark(c, "orderings");
     if ((rc = choose_format(c))) {
         free_index(c);
         return rc;
     }
+    trace_mark(c, "format");
     const int fmt = want_format(c);
     if (fmt != HVS_FMT_NONE && (rc = build_tiles_chain(c, fmt))) {
         free_index(c);
         return rc;
     }
+    trace_mark(c, "tiles");
     if (fmt != HVS_FMT_NONE && !c->have_index) free_index(c);  // no format has a usable bound: exact engine only
     if (fmt == HVS_FMT_NONE) c->have_index = true;              // (orderings only: the exact engine's range scans)
     if (c->have_index && c->tile_fmt != HVS_FMT_NONE && c->engine == HVS_ENGINE_AUTO && n >= kMfmaMinRows) {
@@ -852,6 +876,7 @@ int build_index(hvs_ctx* c)
             free_index(c);
             return rc;
         }
+        trace_mark(c, "probe");
     }
     return HVS_OK;
 }
@@ -913,6 +938,10 @@ int ensure_filter_workspace(hvs_ctx* c, uint32_t nqb, uint32_t want_fcap = HVS_F
     B.ngroups = groups;
     B.fcap = (uint32_t)std::min<size_t>(16384u, c->fb_cand_entries / slots);
     B.gcap = (uint32_t)std::min<size_t>((size_t)HVS_GROUP * 16384u, c->fb_pair_entries / groups);
+    if (c->force_pfail) {  // planner probe: a full batch's list capacity, whatever a larger workspace would offer this small batch
+        B.fcap = std::min<uint32_t>(B.fcap, HVS_FCAP);
+        B.gcap = std::min<uint32_t>(B.gcap, HVS_GCAP);
+    }
     B.knn = c->k;
     B.topcap = c->k <= 128u ? 128u : 256u;
     // sort workspace shared with the exact engine
@@ -1146,7 +1175,7 @@ int run_batch_mfma(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const uin
         for (bool& h : c->guess_have) h = false;
         c->guess_k = c->k;
     }
-    const uint32_t gslot = proven_last ? 0u : guess_pfail_for(nqb);  // slot 0: the proven table
+    const uint32_t gslot = proven_last ? 0u : (c->force_pfail ? c->force_pfail : guess_pfail_for(nqb));  // slot 0: the proven table
     if (!c->guess_have[gslot]) {
         c->guess_tab[gslot] = plan_guess(c->k, proven_last, gslot ? gslot : 3u);
         c->guess_have[gslot] = true;
@@ -1346,7 +1375,8 @@ int resolve_overflow(hvs_ctx* c)
 void staging_copy(void* dst, const void* src, size_t bytes)
 {
     static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned parts = bytes >= (4u << 20) ? std::min(4u, std::max(1u, hw / 4u)) : 1u;
+    static const unsigned kMaxParts = env_u32("HVS_STAGE_THREADS", 8u, 1u, 64u);  // (4 until round 4: ~15 GB/s; 8: ~25 GB/s on the GPU boxes' hosts)
+    const unsigned parts = bytes >= (4u << 20) ? std::min(kMaxParts, std::max(1u, hw / 4u)) : 1u;
     if (parts <= 1u) {
         std::memcpy(dst, src, bytes);
         return;
@@ -1571,6 +1601,20 @@ int leaf_create(hvs_ctx** out, int device)
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ovf), 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     c->h_ovf[0] = c->h_ovf[1] = 0u;
+    // The first operation on a stream creates its hardware queue (and the first copy in each direction its DMA path): a few
+    // milliseconds that belong here, not inside the first query (round 3's cold hvs_query of 10^4 queries took 8 ms for 2 ms
+    // of device work).
+    (void)hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemsetAsync(c->d_ovf_count, 0, 2 * sizeof(uint32_t), c->spare.stream);
+    (void)hipStreamSynchronize(c->spare.stream);
+    (void)hipMemcpyAsync(c->d_ovf_count, c->h_ovf, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, c->s_in);
+    (void)hipStreamSynchronize(c->s_in);
+    (void)hipMemcpyAsync(c->h_ovf, c->d_ovf_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_out);
+    (void)hipEventRecord(c->ev_batch, c->stream);
+    (void)hipStreamWaitEvent(c->s_out, c->ev_batch, 0);
+    (void)hipStreamSynchronize(c->s_out);
+    (void)hipGetLastError();
     *out = c;
     return HVS_OK;
 }
@@ -1624,6 +1668,19 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     if (rc) return rc;
     // pinned staging of the host path (ids only: the distance slots follow the first call that asks for distances)
     if ((rc = ensure_staging(c, false, nq, nq))) return rc;
+    if (!c->dma_warm && c->h_out_ids[0] && c->h_in[0] && c->d_out_ids && c->d_q) {
+        // the first DMA-sized copy in each direction sets up its engine queue (a cold 4 MB D2H took 6 ms): here, not in the first query
+        const size_t bytes = std::min<size_t>((size_t)1 << 20, std::min((size_t)c->out_cap_q[0] * c->stage_k * sizeof(uint32_t),
+                                                                      (size_t)c->in_cap_q[0] * HVS_QCOLS * sizeof(float)));
+        if (bytes && (size_t)nq * c->k * sizeof(uint32_t) >= bytes) {
+            (void)hipMemcpyAsync(c->h_out_ids[0], c->d_out_ids, bytes, hipMemcpyDeviceToHost, c->s_out);
+            (void)hipMemcpyAsync(c->d_q, c->h_in[0], bytes, hipMemcpyHostToDevice, c->s_in);
+            (void)hipStreamSynchronize(c->s_out);
+            (void)hipStreamSynchronize(c->s_in);
+            (void)hipGetLastError();
+            c->dma_warm = true;
+        }
+    }
     // (the filter workspace only when a filter engine is going to run: 4096 <= n < 32768 under AUTO has an index for the
     // range scans of the exact engine, whose batches are kBatch queries)
     const bool filter_runs = c->have_index && (c->engine == HVS_ENGINE_MFMA_FILTER || c->engine == HVS_ENGINE_MFMA_I8 ||
@@ -1690,6 +1747,7 @@ int finish_data(hvs_ctx* c)
     HVS_HIP(c, hipEventElapsedTime(&ms, c->ev_q0, c->ev_q1));
     c->index_ms = ms;
     c->load_ms += ms;
+    trace_mark(c, "index");
     if (c->reserve_nq) {  // the caller announced its call size (hvs_reserve)
         // not fatal: D and the index are loaded; the first query allocates what it needs (or reports the failure itself)
         if (leaf_reserve(c, c->reserve_nq) == HVS_ENOMEM) {
@@ -1792,6 +1850,7 @@ int leaf_upload_data(hvs_ctx* c, const float* rows, uint32_t n)
 {
     int rc = begin_data(c, n);
     if (rc) return rc;
+    trace_mark(c, "alloc");
     HVS_HIP(c, hipEventRecord(c->ev_q0, c->stream));
     if ((rc = upload_rows(c, c->d_data, rows, (size_t)n * HVS_DCOLS))) return rc;
     HVS_HIP(c, hipEventRecord(c->ev_q1, c->stream));
@@ -1802,9 +1861,15 @@ int leaf_upload_data(hvs_ctx* c, const float* rows, uint32_t n)
 
 int leaf_load_data(hvs_ctx* c, const float* rows, uint32_t n)
 {
+    HostTrace tr;
+    c->trace = &tr;
     int rc = leaf_upload_data(c, rows, n);
-    if (rc) return rc;
-    return finish_data(c);
+    trace_mark(c, "upload");
+    if (!rc) rc = finish_data(c);
+    trace_mark(c, "done");
+    tr.flush("hvs_load_data", n);
+    c->trace = nullptr;
+    return rc;
 }
 
 // D replicated from another GPU's copy (xGMI peer copy; same-device contexts: a device-to-device copy)
@@ -2009,6 +2074,7 @@ int leaf_query(hvs_ctx* c, const float* q_rows, uint32_t nq, float sample_propor
         if (r2) return r2;
         HVS_HIP(c, hipEventRecord(c->ev_stage, c->s_in));
         if (wait_here) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage, 0));
+        if (staged_q == 0u) tr.mark("in0");
         staged_q = std::min(nq, in_next * SQ);
         return HVS_OK;
     };

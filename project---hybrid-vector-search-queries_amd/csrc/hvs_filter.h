@@ -666,8 +666,11 @@ struct HvsBatch {
 // failure inside such a retry batch): the exact engine answers it.  The larger code wins.
 #define HVS_FAIL_RETRY 1u
 #define HVS_FAIL_EXACT 2u
-__device__ __forceinline__ void hvs_flag_fail(const uint32_t code, uint32_t* __restrict__ overflow, uint32_t slot)
+__device__ __forceinline__ void hvs_flag_fail(uint32_t code, uint32_t* __restrict__ overflow, uint32_t slot)
 {
+    // `code` is a kernel argument (wave-uniform): it stays in its scalar register up to this rare path -- hoisted into a vector
+    // register in front of the row loop it cost hvs_k_seed_exact its 169th register, i.e. a spill
+    asm volatile("" : "+s"(code));
     if (overflow[slot] < code) overflow[slot] = code;  // (racing writers of one batch all write the same code)
 }
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r04j
+mkdir -p $OUT
+cd $ROOT
+for p in 1 2 3 4; do
+HVS_TRACE=1 timeout -k 10 300 python bench.py --profile $p --steps 2 --warmup 1 --cpu-seconds 0 --no-e2e --no-fixed-q --no-configs12 > $OUT/bench_profile${p}_auto.json 2>$OUT/bench_profile${p}_auto.err || echo "profile $p failed"
+grep "planner" $OUT/bench_profile${p}_auto.err | head -4
+python - <<PY
+import json
+o=json.load(open("$OUT/bench_profile${p}_auto.json")); r=o["roofline"]
+print("profile $p auto: %.0f q/s  frac %.3f  rescored/query %.0f  retried %d  exact fallback %d  engine %d" % (o["value"], r["frac"], r["rescored_pairs_per_query"], r["retry_queries"], r["fallback_queries"], o["config"]["engine"]))
+PY
+done
+echo done

@@ -69,6 +69,10 @@ def oracle():
     lib.hvs_oracle_vec_query_knn.restype = C.c_int
     lib.hvs_oracle_vec_query_knn.argtypes = [_f32p, C.c_uint32, _f32p, C.c_uint32, C.c_float, _u32p, _f32p,
                                              C.c_int, C.c_int, C.c_int]
+    lib.hvs_oracle_pin_threads.restype = None
+    lib.hvs_oracle_pin_threads.argtypes = [C.c_int]
+    lib.hvs_oracle_place_rows.restype = C.c_int
+    lib.hvs_oracle_place_rows.argtypes = [_f32p, _f32p, C.c_uint32, C.c_float, C.c_int, C.c_int]
     lib.hvs_oracle_vec_query_baseline.restype = C.c_int
     lib.hvs_oracle_vec_query_baseline.argtypes = [_f32p, C.c_uint32, _f32p, C.c_uint32, C.c_float, _u32p, _f32p]
     lib.hvs_oracle_dist_file_values.restype = None
@@ -139,6 +143,40 @@ def oracle_query(nodes, queries, sample_proportion=1.0, engine="canonical", thre
     if rc != 0:
         raise ValueError(f"oracle rejected the input (rc={rc})")
     return ids, dists
+
+
+def oracle_place_rows(nodes, sample_proportion=1.0, part_threads=0, hw_threads=8):
+    """A copy of D whose partitions were first touched by the threads that scan them in the `knn` engine (NUMA placement for
+    the timed CPU baseline; hvs_oracle_place_rows).  Returns (copy, threads)."""
+    nodes = _c(nodes, np.float32)
+    out = np.empty_like(nodes)                                   # untouched pages: the copy below places them
+    t = oracle().hvs_oracle_place_rows(_fp(out), _fp(nodes), nodes.shape[0], sample_proportion, part_threads, hw_threads)
+    return out, int(t)
+
+
+def passing_rows_per_query(nodes, queries):
+    """m(q) of SURVEY 8d -- rows of D passing each query's predicate (optimized_parallel.hpp:105-138) -- from sorted attribute
+    columns instead of nq x n predicate evaluations."""
+    n = nodes.shape[0]
+    cat, ts = nodes[:, 0], nodes[:, 1]
+    order = np.lexsort((ts, cat))
+    cat_s, ts_s = cat[order], ts[order]
+    t_sorted = np.sort(ts)
+    out = np.zeros(len(queries), np.int64)
+    for i, q in enumerate(queries):
+        typ = np.uint32(q[0]) if q[0] >= 0 else np.uint32(0xFFFFFFFF)
+        v = np.float32(np.int32(q[1])) if abs(q[1]) < 2**31 else np.float32(np.nan)
+        l, r = q[2], q[3]
+        if typ == 0:
+            out[i] = n
+        elif typ == 1:
+            out[i] = np.searchsorted(cat_s, v, "right") - np.searchsorted(cat_s, v, "left")
+        elif typ == 2:
+            out[i] = max(0, np.searchsorted(t_sorted, r, "right") - np.searchsorted(t_sorted, l, "left"))
+        elif typ == 3:
+            a, b = np.searchsorted(cat_s, v, "left"), np.searchsorted(cat_s, v, "right")
+            out[i] = max(0, np.searchsorted(ts_s[a:b], r, "right") - np.searchsorted(ts_s[a:b], l, "left"))
+    return out
 
 
 def oracle_dists_for_ids(nodes, queries, ids, order="simd"):

@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the oracle and the committed goldens.
 Runs on the GPU box: `pytest -m gpu`.  Bit-exact bar: distance sequences identical, ids
 identical outside equal-distance tie groups."""
+import ctypes as C
 import glob
 import importlib
 import os
@@ -925,20 +926,31 @@ def test_config3_host_path_4e6_queries_one_call():
 
 
 def test_d1e8_config4_hbm_sizing():
-    """BASELINE configs[4], one GPU's view of it: D = 10^8 rows resident (40.8 GB of rows + the INT8 index), 2^18 mixed
-    queries through HVS_ENGINE_AUTO: filter engine, no fallbacks, sorted distances, predicate / padding properties on
-    every answer, bit-equality with the exact-scan engine on 1024 queries and with the oracle on 32 queries per type."""
-    n, nq = 100_000_000, 1 << 18
+    """BASELINE configs[4], one GPU's view of it: D = 10^8 rows resident (40.8 GB of rows + the INT8 index) and a rank's REAL share
+    of the 10^7-query set on an 8-GPU node -- 1.25 x 10^6 mixed queries -- as ONE hvs_query call from host memory to host memory
+    (schedule = hvs_plan_batches(1250000, 1): 2^18 first and last, the rest in between, consecutive batches on two lanes).
+    Filter engine, no fallbacks; the ids equal the device-resident path's; sorted distances, predicate / padding properties on
+    every answer; bit-equality with the exact-scan engine on 1024 queries and with the oracle on 64 queries per type."""
+    n, nq = 100_000_000, 1_250_000
+    lib = PKG.library()
+    sched = (C.c_uint32 * 16)()
+    nb = lib.hvs_plan_batches(nq, 1, sched, 16)
+    assert nb >= 3 and sum(sched[:nb]) == nq and sched[0] == sched[nb - 1] == 1 << 18 and max(sched[:nb]) <= 1 << 21, list(sched[:nb])
     with PKG.Engine(0) as e:
+        e.reserve(nq)
         e.gen_data(n, T.SEED_DATA, T.GEN_V1, 100)
         e.gen_queries(nq, T.SEED_QUERY + 9, T.GEN_V1, 100, -1, 0)
         queries = e.download_queries(0, nq)
-        e.query_resident(0, nq, 1.0)
-        e.sync()
+        ids, dists = e.query(queries, 1.0)                         # host -> host, one call
         t = e.last_timing()
-        ids, dists = e.download_results(0, nq)
         assert t.engine in FILTER_ENGINES and t.fallback_queries == 0 and t.nq == nq
-        print("D=1e8: %d queries in %.0f ms on the device, %.0f rescored pairs per query" % (nq, t.query_ms, t.rescored_pairs / nq))
+        print("D=1e8: %d queries host->host in %.0f ms (%.0f on the device), %.0f rescored pairs per query, %d retried, %d filter launches"
+              % (nq, t.host_ms, t.query_ms, t.rescored_pairs / nq, t.retry_queries, t.main_kernel_launches))
+        e.query_resident(0, nq, 1.0)                               # the resident path on the queries the host path left in HBM
+        e.sync()
+        ids_r, dists_r = e.download_results(0, nq)
+        assert np.array_equal(ids, ids_r) and np.array_equal(dists.view(np.uint32), dists_r.view(np.uint32))
+        del ids_r, dists_r
         sel = np.arange(0, nq, nq // 1024)[:1024]
         e.set_engine(PKG.ENGINE_EXACT_SCAN)
         ids_x, d_x = e.query(queries[sel], 1.0)
@@ -956,7 +968,7 @@ def test_d1e8_config4_hbm_sizing():
     assert np.all(((tt >= queries[has_t, 2:3]) & (tt <= queries[has_t, 3:4]))[notpad[has_t]])
     for row in ids[typ == 0][::997]:
         assert len(set(row.tolist())) == 100
-    pick = np.concatenate([np.nonzero(typ == k)[0][:32] for k in range(4)])           # 128 queries against the oracle
+    pick = np.concatenate([np.nonzero(typ == k)[0][:64] for k in range(4)])           # 256 queries against the oracle
     assert np.array_equal(T.oracle_dists_for_ids(nodes, queries[pick], ids[pick]).view(np.uint32), dists[pick].view(np.uint32))
     ref, _ = T.oracle_query(nodes, queries[pick], threads=32)
     T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
