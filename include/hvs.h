@@ -68,6 +68,7 @@ typedef struct hvs_timing {
     uint32_t flags;            /* HVS_TIMING_* bits                                                                     */
 } hvs_timing;
 #define HVS_TIMING_INDEX_TOO_LARGE 1u /* the data set has more than 2^29 rows per GPU: no filter index, exact engine only */
+#define HVS_TIMING_I8_ROTATED 4u      /* the INT8 tiles that ran were cut from the rotated vectors (csrc/hvs_filter.h, HvsQuant): same answers */
 #define HVS_TIMING_FORMAT_CHANGED 2u  /* HVS_ENGINE_AUTO: so many queries of this call had no usable INT8 bound (far outside the
                                          data's box) that the 16-bit float tiles were built in mid-call; later calls use them */
 

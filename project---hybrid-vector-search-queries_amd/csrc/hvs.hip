@@ -113,6 +113,8 @@ struct hvs_ctx : HvsLane {
     int tile_fmt = HVS_FMT_NONE;                          // format of the tiles currently built
     int planned_fmt = HVS_FMT_BF16;                       // what HVS_ENGINE_AUTO uses for this data set
     bool i8_usable = false;
+    bool i8_rot = false;       // the INT8 centre / scale (d_quant) and tiles live in the rotated space (HvsQuant::rot)
+    bool i8_rot_built = false; // ... and the INT8 tiles currently built were cut from it
     bool i8_rejected = false;  // the INT8 tiles were built and their bound was unusable: do not try again
     bool f16_rejected = false; // likewise the FP16 tiles (components beyond the half-precision range)
     double index_ms = 0.0;
@@ -514,6 +516,7 @@ void free_index(hvs_ctx* c)
     c->have_index = false;
     c->tile_fmt = HVS_FMT_NONE;
     c->i8_usable = false;
+    c->i8_rot = false;
     c->i8_rejected = false;
     c->f16_rejected = false;
 }
@@ -525,15 +528,37 @@ void free_index(hvs_ctx* c)
 // below the mean the k-th neighbour of n rows sits.  Everything here is an estimate from a sample of rows and a
 // unimodal model of the distances -- build_index checks the choice with a probe batch (probe_format) -- and it decides
 // speed only: all formats give the same answers.
+// HVS_I8_ROTATE: 0 = INT8 tiles never rotated, 1 = always (HVS_FMT_I8X16), unset = the planner's probe decides (read per
+// data set, so that a test can switch it between contexts)
+int rotate_policy()
+{
+    const char* v = std::getenv("HVS_I8_ROTATE");
+    if (!v || !*v) return -1;
+    return std::atoi(v) != 0 ? 1 : 0;
+}
+
+// centre and scale of the INT8 format over the vector components (`rot` false) or over their rotated images (HvsQuant)
+int set_quant(hvs_ctx* c, bool rot)
+{
+    if (!c->d_quant) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_quant), sizeof(HvsQuant)));
+    hipLaunchKernelGGL(hvs_k_quant_reset, dim3(1), dim3(128), 0, c->stream, c->d_quant, rot ? 1u : 0u);
+    if (rot)
+        hipLaunchKernelGGL(hvs_k_minmax_rot, dim3(std::min(c->n, 4096u)), dim3(128), 0, c->stream, c->d_data, c->n, c->d_quant);
+    else
+        hipLaunchKernelGGL(hvs_k_minmax, dim3(std::min(c->n, 4096u)), dim3(128), 0, c->stream, c->d_data, c->n, c->d_quant);
+    hipLaunchKernelGGL(hvs_k_quant_params, dim3(1), dim3(128), 0, c->stream, c->d_quant);
+    HVS_HIP(c, hipGetLastError());
+    c->i8_rot = rot;
+    return HVS_OK;
+}
+
 int choose_format(hvs_ctx* c)
 {
     const uint32_t n = c->n;
     c->planned_fmt = HVS_FMT_F16;
     c->i8_usable = false;
-    if (!c->d_quant) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_quant), sizeof(HvsQuant)));
-    hipLaunchKernelGGL(hvs_k_quant_reset, dim3(1), dim3(128), 0, c->stream, c->d_quant);
-    hipLaunchKernelGGL(hvs_k_minmax, dim3(std::min(n, 4096u)), dim3(128), 0, c->stream, c->d_data, n, c->d_quant);
-    hipLaunchKernelGGL(hvs_k_quant_params, dim3(1), dim3(128), 0, c->stream, c->d_quant);
+    int rcq = set_quant(c, false);  // (the model below prices the plain INT8 format; HVS_I8_ROTATE=1 switches afterwards)
+    if (rcq) return rcq;
     if (!c->d_bounds) HVS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_bounds), sizeof(HvsBounds)));
     HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
     const uint32_t step = std::max(1u, n / 65536u);
@@ -578,6 +603,14 @@ int choose_format(hvs_ctx* c)
         if (!std::strcmp(f, "f16")) c->planned_fmt = HVS_FMT_F16;
         if (!std::strcmp(f, "i8")) c->planned_fmt = kI8Fmt;
     }
+    if (rotate_policy() == 1 && kI8Fmt == HVS_FMT_I8X16 && c->i8_usable) {
+        if ((rcq = set_quant(c, true))) return rcq;
+        double sdr = 0.0;
+        HVS_HIP(c, hipMemcpyAsync(&sdr, reinterpret_cast<const char*>(c->d_quant) + offsetof(HvsQuant, sd), sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HVS_HIP(c, hipStreamSynchronize(c->stream));
+        if (!(sdr > 0.0 && std::isfinite(sdr)) && (rcq = set_quant(c, false))) return rcq;
+    }
     return HVS_OK;
 }
 
@@ -606,7 +639,12 @@ int build_tiles(hvs_ctx* c, int fmt)
     if (!c->d_bpos_t && (rc = dev_alloc(c, &c->d_bpos_t, (size_t)L.nblk))) return rc;
     HVS_HIP(c, hipMemsetAsync(c->d_bounds, 0, sizeof(HvsBounds), c->stream));
     const dim3 grid((L.nblk + 3u) / 4u);
-    if (fmt == HVS_FMT_I8X16) {
+    if (fmt == HVS_FMT_I8X16 && c->i8_rot) {
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8x16_rot, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_quant,
+                           c->d_tiles_ct, reinterpret_cast<int*>(c->d_nrm_ct), c->d_bpos_ct, c->d_bounds);
+        hipLaunchKernelGGL(hvs_k_build_tiles_i8x16_rot, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_quant,
+                           c->d_tiles_t, reinterpret_cast<int*>(c->d_nrm_t), c->d_bpos_t, c->d_bounds);
+    } else if (fmt == HVS_FMT_I8X16) {
         hipLaunchKernelGGL(hvs_k_build_tiles_i8x16, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_ct, L, c->d_quant,
                            c->d_tiles_ct, reinterpret_cast<int*>(c->d_nrm_ct), c->d_bpos_ct, c->d_bounds);
         hipLaunchKernelGGL(hvs_k_build_tiles_i8x16, grid, dim3(256), 0, c->stream, c->d_data, n, c->d_perm_t, L, c->d_quant,
@@ -646,6 +684,7 @@ int build_tiles(hvs_ctx* c, int fmt)
     if (!ok) return HVS_OK;  // have_index stays false
     c->tile_fmt = fmt;
     c->have_index = true;
+    c->i8_rot_built = HVS_IS_I8(fmt) && c->i8_rot;
     return HVS_OK;
 }
 
@@ -778,18 +817,40 @@ int plan_by_probe(hvs_ctx* c)
     if (rc) return rc;
     if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
     int best = c->tile_fmt;
+    bool best_rot = c->i8_rot;
     double best_cost = cost;
     // INT8 tiles stay unless their band visibly lets too much through on this data (the cost formula is not trusted to
-    // split hairs between formats that both work: at small n everything is launch latency)
-    if (HVS_IS_I8(c->tile_fmt) && (infl > 2.5 || failed > 0.01) && !c->f16_rejected) {
+    // split hairs between formats that both work: at small n everything is launch latency).  Otherwise the candidates are
+    // probed in turn -- the rotated INT8 tiles (same filter rate; HvsQuant), then the FP16 tiles (half the rate, an 8x tighter
+    // band) -- and the cheapest stays.
+    if (HVS_IS_I8(c->tile_fmt) && (infl > 2.5 || failed > 0.01)) {
         const int had = c->tile_fmt;
-        if ((rc = build_tiles_chain(c, HVS_FMT_F16))) return rc;
-        if (c->have_index && (rc = probe_format(c, &cost, &infl, &failed))) return rc;
-        if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
-        if (c->have_index && cost < best_cost) {
-            best = c->tile_fmt;
-            best_cost = cost;
-        } else if ((rc = build_tiles_chain(c, had))) {
+        const bool had_rot = c->i8_rot;
+        if (had == HVS_FMT_I8X16 && !had_rot && rotate_policy() != 0) {
+            if ((rc = set_quant(c, true))) return rc;
+            if ((rc = build_tiles(c, had))) return rc;
+            if (c->have_index) {
+                if ((rc = probe_format(c, &cost, &infl, &failed))) return rc;
+                if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d (rotated) cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
+                if (cost < best_cost) {
+                    best_rot = true;
+                    best_cost = cost;
+                }
+            }
+        }
+        if (!c->f16_rejected) {
+            if ((rc = build_tiles_chain(c, HVS_FMT_F16))) return rc;
+            if (c->have_index && (rc = probe_format(c, &cost, &infl, &failed))) return rc;
+            if (kTrace) std::fprintf(stderr, "[hvs trace] planner probe: format %d cost %.3f inflation %.2f failed %.4f\n", c->tile_fmt, cost, infl, failed);
+            if (c->have_index && cost < best_cost) {
+                best = c->tile_fmt;
+                best_cost = cost;
+            }
+        }
+        if (HVS_IS_I8(best)) {  // an INT8 variant stays: its centre / scale and tiles come back if something else was built last
+            if (c->i8_rot != best_rot && (rc = set_quant(c, best_rot))) return rc;
+            if ((c->tile_fmt != best || !c->have_index || c->i8_rot_built != best_rot) && (rc = build_tiles_chain(c, had))) return rc;
+        } else if (c->i8_rot && (rc = set_quant(c, false))) {  // (a later change of engine finds the plain INT8 parameters)
             return rc;
         }
     }
@@ -1531,7 +1592,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
                           : HVS_ENGINE_EXACT_SCAN;
     c->timing.load_ms = c->load_ms;
     c->timing.n_gpus = 1;
-    c->timing.flags = c->index_too_large ? HVS_TIMING_INDEX_TOO_LARGE : 0u;
+    c->timing.flags = (c->index_too_large ? HVS_TIMING_INDEX_TOO_LARGE : 0u) | (mfma && HVS_IS_I8(c->tile_fmt) && c->i8_rot_built ? HVS_TIMING_I8_ROTATED : 0u);
     c->timing_valid = true;
     return HVS_OK;
 }

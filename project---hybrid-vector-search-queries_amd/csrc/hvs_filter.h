@@ -304,11 +304,51 @@ struct HvsBounds {  // global maxima over rows, all rounded up
 // data widens it, which only costs re-scoring work, never correctness -- the planner (hvs.hip,
 // choose_format) estimates that cost from a sample of row pairs.
 // ---------------------------------------------------------------------------------------------
+// Rotated INT8 tiles (round 4; HVS_FMT_I8X16 only).  One scale for all dimensions is set by the widest one: vectors whose
+// variance sits in a few dimensions (PCA-like spectra) spend the 8 bits of every other dimension on nothing and the band
+// |sd qq| E_D + e_q N_D grows with sd sqrt(100).  Distances are invariant under y = R x with R^T R = I, so rows and queries
+// are first mapped to 128 dimensions by  y = H S pad(x) / sqrt(128)  (S = fixed signs, H = the 128-point Walsh-Hadamard
+// matrix, pad = 28 zeros: the K slots the INT8 fragments pad with anyway): every y_k is a signed average of all 100
+// components, the per-dimension ranges come out nearly equal, and the same bound (centre, one scale, exact integer chain,
+// clip term) holds verbatim on the y's -- R has orthonormal columns, so |R q - R d| = |q - d| in real arithmetic; the y's are
+// evaluated in f64 (relative error ~1e-14, inside the 1e-9 slack hvs_k_merge keeps for its own f64 evaluation).
+// Measured (profiles/r04/nonuniform_int8.txt): PCA-like data at k/n = 10^-5, rows a band lets through per 30 wanted:
+// 456 plain INT8, 151 rotated, 31 FP16; uniform data 48 / 135 / 31 -- the planner's probe decides per data set.
+#define HVS_RDIM 128
+// sign of input dimension j (a fixed pseudo-random pattern)
+__host__ __device__ static inline uint32_t hvs_rot_sign(uint32_t j) { return ((j + 1u) * 0x9E3779B1u >> 17) & 1u; }
+// component k of the rotated image of the 100-vector x
+template <typename V>
+__device__ __forceinline__ double hvs_rot_elem(const V& x, uint32_t k)
+{
+    double a = 0.0;
+#pragma unroll 4
+    for (uint32_t j = 0; j < HVS_NDIM; ++j) {
+        const double v = (double)x[j];
+        a += ((uint32_t)__popc(k & j) + hvs_rot_sign(j)) & 1u ? -v : v;
+    }
+    return a * 0.08838834764831844055;  // 1 / sqrt(128)
+}
+// f32 neighbours of a double, rounded outward (the box of the rotated data must contain every rotated row)
+__device__ __forceinline__ float hvs_f32_below(double y)
+{
+    float f = (float)y;
+    if ((double)f > y) f = nextafterf(f, -__builtin_inff());
+    return f;
+}
+__device__ __forceinline__ float hvs_f32_above(double y)
+{
+    float f = (float)y;
+    if ((double)f < y) f = nextafterf(f, __builtin_inff());
+    return f;
+}
+
 struct HvsQuant {
-    float center[HVS_NDIM];
+    float center[HVS_RDIM];   // [0, 100) of the vector components, or [0, 128) of the rotated ones (`rot`)
     double sd;       // scale; 0 or non-finite: format unusable
     double inv_sd;
-    uint32_t kmin[HVS_NDIM], kmax[HVS_NDIM];  // per-dimension min / max as order-preserving keys (hvs_attr_key)
+    uint32_t kmin[HVS_RDIM], kmax[HVS_RDIM];  // per-dimension min / max as order-preserving keys (hvs_attr_key)
+    uint32_t rot;    // 1: centre / scale / tiles / fragments live in the rotated space
 };
 
 __host__ __device__ static inline float hvs_attr_key_inv(uint32_t k)
@@ -323,13 +363,34 @@ __host__ __device__ static inline float hvs_attr_key_inv(uint32_t k)
 #endif
 }
 
-__global__ void hvs_k_quant_reset(HvsQuant* __restrict__ qz)
+__global__ void hvs_k_quant_reset(HvsQuant* __restrict__ qz, uint32_t rot)
 {
     const uint32_t k = threadIdx.x;
-    if (k < HVS_NDIM) {
+    if (k < HVS_RDIM) {
         qz->kmin[k] = 0xFFFFFFFFu;
         qz->kmax[k] = 0u;
+        qz->center[k] = 0.0f;
     }
+    if (k == 0u) qz->rot = rot;
+}
+
+// the same in the rotated space: blockDim = 128 (thread = rotated dimension), rows strided over blocks and staged in LDS
+__global__ __launch_bounds__(128) void hvs_k_minmax_rot(const float* __restrict__ D, uint32_t n, HvsQuant* __restrict__ qz)
+{
+    __shared__ float srow[HVS_NDIM];
+    const uint32_t k = threadIdx.x;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();
+        if (k < HVS_NDIM) srow[k] = D[(size_t)i * HVS_DCOLS + 2 + k];
+        __syncthreads();
+        const double y = hvs_rot_elem(srow, k);
+        const uint32_t klo = hvs_attr_key(hvs_f32_below(y)), khi = hvs_attr_key(hvs_f32_above(y));
+        lo = klo < lo ? klo : lo;
+        hi = khi > hi ? khi : hi;
+    }
+    atomicMin(&qz->kmin[k], lo);
+    atomicMax(&qz->kmax[k], hi);
 }
 
 // per-dimension min / max of the vector components; blockDim = 128 (thread = dimension), rows strided over blocks
@@ -349,9 +410,11 @@ __global__ __launch_bounds__(128) void hvs_k_minmax(const float* __restrict__ D,
 
 __global__ void hvs_k_quant_params(HvsQuant* __restrict__ qz)
 {
-    __shared__ double half[HVS_NDIM];
+    __shared__ double half[HVS_RDIM];
     const uint32_t k = threadIdx.x;
-    if (k < HVS_NDIM) {
+    const uint32_t ndim = qz->rot ? HVS_RDIM : HVS_NDIM;
+    if (k < HVS_RDIM) half[k] = 0.0;
+    if (k < ndim) {
         const double lo = (double)hvs_attr_key_inv(qz->kmin[k]), hi = (double)hvs_attr_key_inv(qz->kmax[k]);  // NaN key -> NaN
         const float c = (float)(0.5 * (lo + hi));
         qz->center[k] = c;
@@ -361,7 +424,7 @@ __global__ void hvs_k_quant_params(HvsQuant* __restrict__ qz)
     __syncthreads();
     if (k == 0u) {
         double m = 0.0;
-        for (int i = 0; i < HVS_NDIM; ++i) m = half[i] > m ? half[i] : m;
+        for (int i = 0; i < HVS_RDIM; ++i) m = half[i] > m ? half[i] : m;
         // no row is clipped; all rows equal: any scale works
         double sd = m > 0.0 ? m / 127.0 * (1.0 + 1e-9) : 1.0;
         if (!(sd < 1.0e18) || sd < 1.0e-18) sd = 0.0;  // non-finite or extreme ranges: INT8 format unusable
@@ -495,6 +558,65 @@ __global__ __launch_bounds__(256) void hvs_k_build_tiles_i8x16(const float* __re
             w[p] = word;
         }
         tiles[((size_t)idx * HVS_I8X16_FRAGS + f) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// HVS_FMT_I8X16 tiles of the ROTATED rows (see HvsQuant): one wave per storage block.  The block's 32 rows are staged in LDS,
+// every rotated component is evaluated once (lane = 64 of the block's 4096 components per pass) and kept as int8 in an LDS
+// image the fragments are then cut from; accumulator inits and row bounds as in hvs_k_build_tiles_i8x16, over 128 dimensions.
+__global__ __launch_bounds__(256) void hvs_k_build_tiles_i8x16_rot(const float* __restrict__ D, uint32_t n,
+                                                                   const uint32_t* __restrict__ perm, HvsLevels L,
+                                                                   const HvsQuant* __restrict__ qz, uint4* __restrict__ tiles,
+                                                                   int* __restrict__ norms, uint32_t* __restrict__ blockpos,
+                                                                   HvsBounds* __restrict__ bounds)
+{
+    __shared__ float srow[4][32][HVS_NDIM];
+    __shared__ __attribute__((aligned(16))) signed char s8[4][32][HVS_RDIM];
+    __shared__ double ssum[4][32][2];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t idx = blockIdx.x * 4u + w;
+    const bool live = idx < L.nblk;  // (no early return: the workgroup barriers below)
+    const uint32_t b = live ? hvs_storage_to_block(L, idx) : 0u;
+    if (live && lane == 0u) blockpos[idx] = b;
+    for (uint32_t e = lane; e < 32u * HVS_NDIM; e += 64u) {
+        const uint32_t r = e / HVS_NDIM, c = e % HVS_NDIM;
+        const uint32_t pos = b * 32u + r;
+        srow[w][r][c] = (live && pos < n) ? D[(size_t)perm[pos] * HVS_DCOLS + 2u + c] : 0.0f;
+    }
+    if (lane < 32u) ssum[w][lane][0] = ssum[w][lane][1] = 0.0;
+    __syncthreads();
+    const double sd = qz->sd, inv_sd = qz->inv_sd;
+    for (uint32_t e = lane; e < 32u * HVS_RDIM; e += 64u) {
+        const uint32_t r = e >> 7, k = e & 127u;
+        const bool valid = live && b * 32u + r < n;
+        const double x = hvs_rot_elem(srow[w][r], k) - (double)qz->center[k];
+        const int v = valid ? hvs_quant_i8(x, inv_sd) : 0;
+        s8[w][r][k] = (signed char)v;
+        if (valid) {
+            const double xq = sd * (double)v;
+            atomicAdd(&ssum[w][r][0], x * x);
+            atomicAdd(&ssum[w][r][1], (x - xq) * (x - xq));
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    if (lane < 32u) {
+        const bool valid = b * 32u + lane < n;
+        int nh = HVS_I8_PAD_NORM;
+        if (valid) {
+            const double nd = ssum[w][lane][0], e2 = ssum[w][lane][1];
+            const double v = floor(-0.5 * nd * inv_sd * inv_sd);
+            nh = v > -1.0e9 ? (int)v : HVS_I8_PAD_NORM;
+            hvs_atomic_max_pos(&bounds->e_d8, hvs_round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-30));
+            hvs_atomic_max_pos(&bounds->n_d8, hvs_round_up_f32(sqrt(nd) * (1.0 + 1e-9) + 1e-30));
+        }
+        norms[(size_t)idx * 32u + lane] = nh;
+    }
+#pragma unroll
+    for (int f = 0; f < HVS_I8X16_FRAGS; ++f) {
+        const int rbk = f >> 1, ks = f & 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(&s8[w][16 * rbk + (lane & 15u)][64 * ks + 16 * (int)(lane >> 4)]);
+        tiles[((size_t)idx * HVS_I8X16_FRAGS + f) * 64u + lane] = v;
     }
 }
 
@@ -916,6 +1038,10 @@ __global__ __launch_bounds__(4 * HVS_GROUP) void hvs_k_prep(const float* __restr
 {
     __shared__ uint32_t smin[HVS_GROUP], smax[HVS_GROUP];
     __shared__ unsigned long long spairs;
+    // rotated INT8 tiles (HvsQuant::rot): the int8 image of the group's rotated queries and the per-slot sums over 128 dimensions
+    __shared__ __attribute__((aligned(16))) signed char sq8[HVS_GROUP][HVS_RDIM];
+    __shared__ double srsum[HVS_GROUP][4];  // |q'|^2, |sd qq|^2, |q' - sd qq|^2 (unclipped dimensions), clip term
+    __shared__ int srbad[HVS_GROUP];
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     const uint32_t sl = t >> 2, part = t & 3u;  // slot within the group; quarter of the dimensions
     const uint32_t s = g * HVS_GROUP + sl;
@@ -925,7 +1051,47 @@ __global__ __launch_bounds__(4 * HVS_GROUP) void hvs_k_prep(const float* __restr
     double qn = 0.0, e2 = 0.0, nb2 = 0.0, clipband = 0.0;
     int bad = 0;
     constexpr int kPart = HVS_NDIM / 4;
-    if (qi != 0xFFFFFFFFu) {
+    const bool rot = fmt == HVS_FMT_I8X16 && qz->rot != 0u;  // uniform over the grid
+    if (rot) {
+        // every rotated component of every query of the group once: thread -> (slot e >> 7, dimension e & 127)
+        if (t < HVS_GROUP) {
+            srsum[t][0] = srsum[t][1] = srsum[t][2] = srsum[t][3] = 0.0;
+            srbad[t] = 0;
+        }
+        __syncthreads();
+        const double sd = qz->sd, inv_sd = qz->inv_sd;
+        for (uint32_t e = t; e < HVS_GROUP * HVS_RDIM; e += blockDim.x) {
+            const uint32_t rs = e >> 7, k = e & 127u;
+            const uint32_t qj = B.qid[g * HVS_GROUP + rs];
+            int v = 0;
+            if (qj != 0xFFFFFFFFu) {
+                const float* __restrict__ q = Q + (size_t)qj * HVS_QCOLS + 4;
+                const double x = hvs_rot_elem(q, k) - (double)qz->center[k];
+                v = hvs_quant_i8(x, inv_sd);
+                const double xq = sd * (double)v;
+                atomicAdd(&srsum[rs][0], x * x);
+                atomicAdd(&srsum[rs][1], xq * xq);
+                if (fabs(x * inv_sd) <= 127.5) {
+                    atomicAdd(&srsum[rs][2], (x - xq) * (x - xq));
+                } else if (x == x) {
+                    const double c = (double)qz->center[k];
+                    const double lo = fabs((double)hvs_attr_key_inv(qz->kmin[k]) - c), hi = fabs((double)hvs_attr_key_inv(qz->kmax[k]) - c);
+                    atomicAdd(&srsum[rs][3], fabs(x - xq) * (lo > hi ? lo : hi) * (1.0 + 1e-9));
+                } else {
+                    srbad[rs] = 1;  // NaN component
+                }
+            }
+            sq8[rs][k] = (signed char)v;
+        }
+        __syncthreads();
+        if (part == 0u) {  // (the shuffles below add three zeros to these)
+            qn = srsum[sl][0];
+            nb2 = srsum[sl][1];
+            e2 = srsum[sl][2];
+            clipband = srsum[sl][3];
+            bad = srbad[sl];
+        }
+    } else if (qi != 0xFFFFFFFFu) {
         const float* __restrict__ q = Q + (size_t)qi * HVS_QCOLS + 4;
         if (HVS_IS_I8(fmt)) {
             // relative to the centre: qn = |q'|^2, nb2 = |sd qq|^2, e2 = |q' - sd qq|^2 over the unclipped dimensions
@@ -1015,6 +1181,16 @@ __global__ __launch_bounds__(4 * HVS_GROUP) void hvs_k_prep(const float* __restr
         B.paircnt[g] = 0;
         B.goverflow[g] = 0;
         if (count_pairs && spairs) atomicAdd(&counters[0], spairs);
+    }
+    if (rot) {
+        // B fragments cut from the int8 image of the rotated queries (all 128 K slots carry data)
+        constexpr uint32_t kSub = HVS_GROUP / HVS_I8X16_QSUB;
+        for (uint32_t e = t; e < kSub * 2u * 64u; e += blockDim.x) {
+            const uint32_t j = e / 128u, ks = (e / 64u) & 1u, l = e & 63u;
+            B.bfrag[((size_t)(g * kSub + j) * 2u + ks) * 64u + l] =
+                *reinterpret_cast<const uint4*>(&sq8[j * HVS_I8X16_QSUB + (l & 15u)][64u * ks + 16u * (l >> 4)]);
+        }
+        return;
     }
     if (fmt == HVS_FMT_I8X16) {
         // B fragments of v_mfma_i32_16x16x64_i8: fragment (sub-block j of 16 queries, k-step ks): lane l holds query

@@ -1172,3 +1172,49 @@ def test_one_context_many_calls_fuzz():
             assert bad.size == 0, (i, {k: v for k, v in st.items() if k != "q"}, len(st["q"]), bad[:8], t.as_dict())
             print("call", i, "nq", len(st["q"]), {k: v for k, v in st.items() if k != "q"}, "ran", t.engine, "flags", t.flags,
                   "retried", t.retry_queries, "exact", t.fallback_queries)
+
+
+@pytest.mark.parametrize("profile", [T.GEN_V1, T.GEN_CLUSTER, T.GEN_PCA, T.GEN_HEAVY, T.GEN_V1_OUT], ids=["v1", "clustered", "pca", "heavy_tails", "v1_out_of_box"])
+def test_rotated_int8_tiles_parity(profile):
+    """Round 4: INT8 tiles cut from the ROTATED vectors (signs + 128-point Walsh-Hadamard transform, csrc/hvs_filter.h HvsQuant) --
+    forced with HVS_I8_ROTATE=1 on every vector law, queries outside the data's box included -- answer bit for bit what the exact
+    engine answers; on PCA-like data they re-score fewer pairs than the plain INT8 tiles (why the planner's probe may pick them)."""
+    n, nq = 400_000, 6144
+    with PKG.Engine(0) as x:
+        x.set_engine(PKG.ENGINE_EXACT_SCAN)
+        x.gen_data(n, T.SEED_DATA, profile, 100)
+        x.gen_queries(nq, T.SEED_QUERY, profile, 100, -1, 0)
+        queries = x.download_queries(0, nq)
+        nodes = x.download_data(0, n)
+        want_i, want_d = x.query(queries, 1.0)
+    pairs = {}
+    old = os.environ.get("HVS_I8_ROTATE")
+    try:
+        for rot in ("0", "1"):
+            os.environ["HVS_I8_ROTATE"] = rot
+            with PKG.Engine(0) as e:
+                e.set_engine(PKG.ENGINE_MFMA_I8)
+                e.load_data(nodes)
+                ids, d = e.query(queries, 1.0)
+                t = e.last_timing()
+                assert t.engine == PKG.ENGINE_MFMA_I8 and bool(t.flags & 4) == (rot == "1"), (rot, t.as_dict())
+                bad = np.nonzero((ids != want_i).any(axis=1) | (d.view(np.uint32) != want_d.view(np.uint32)).any(axis=1))[0]
+                assert bad.size == 0, (rot, bad[:8], t.as_dict())
+                pairs[rot] = t.rescored_pairs / nq
+                print("profile", profile, "rotated" if rot == "1" else "plain", "rescored/query %.0f" % pairs[rot], "retried", t.retry_queries,
+                      "exact", t.fallback_queries)
+                # a second, smaller call on the same context (resident path)
+                e.upload_queries(queries[:777])
+                e.query_resident(0, 777, 1.0)
+                e.sync()
+                ids2, d2 = e.download_results(0, 777)
+                assert np.array_equal(ids2, want_i[:777]) and np.array_equal(d2.view(np.uint32), want_d[:777].view(np.uint32))
+    finally:
+        if old is None:
+            os.environ.pop("HVS_I8_ROTATE", None)
+        else:
+            os.environ["HVS_I8_ROTATE"] = old
+    if profile == T.GEN_PCA:
+        assert pairs["1"] < 0.7 * pairs["0"], pairs
+    ref, _ = T.oracle_query(nodes, queries[:48], threads=8)
+    T.check_parity(nodes, queries[:48], want_i[:48], ref, got_dists=want_d[:48])
