@@ -5,18 +5,20 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
 
 Workload (BASELINE.json metric: queries/sec + recall@100 on D=10^7, Q=4x10^6, dim=100, k=100):
-D = 10^7 gen-v1 rows replicated in every GPU's HBM; the 4x10^6-query set is streamed in batches (2^21, the largest
-batch the library forms, by default: 2 steps = the whole query set);
-one STEP = one pass of the hot path over one batch of `--batch` mixed-type queries per GPU
-(inputs resident in HBM when the timed region starts, result ids gathered to rank 0 over RCCL
-inside the timed region when N > 1).  "end_to_end" repeats the same batches from host memory to host memory
-(the reference's own timing scope, PCIe-inclusive; never `value`).  Queries shard across ranks with no data-path collective
-(weak scaling: per-GPU work is fixed).  value = queries all ranks answered / max-over-ranks time.
+D = 10^7 gen-v1 rows replicated in every GPU's HBM; one STEP = one pass of the hot path over one batch of `--batch` (2^21, the
+largest batch the library forms) mixed-type queries per GPU, inputs resident in HBM when the timed region starts.  The K timed
+steps are library calls over several batches each (N = 1: one call; N > 1: calls of ~K/4 batches, every batch's ids gathered to
+rank 0 over RCCL inside the timed region, under the next call's compute): consecutive batches of a call run on two lanes.
+Queries shard across ranks with no data-path collective (weak scaling: per-GPU work is fixed); value = queries all ranks
+answered / max-over-ranks time.
 
-Extra JSON objects: "roofline" for the dominant kernel (HIP-event kernel time measured live on the
-library's own stream) and "cpu_baseline" (the oracle's reference-faithful threaded engine timed on
-this host's cores over a bounded query sample, rank 0 at N=1 only), plus "recall_at_100" of the
-GPU answers against that oracle sample.
+Extra JSON objects: "roofline" for the dominant kernel (HIP-event kernel time measured live on the library's own streams),
+"end_to_end" (the same batches host memory -> host memory: the reference's own timing scope, PCIe-inclusive; never `value`),
+"fixed_q" (BASELINE's ONE 4x10^6-query set: N = 1 -- the shares of 1/2/4/8 ranks run on this GPU; N > 1 -- run for real: shares
+from host memory, RCCL gather to rank 0, sampled check on rank 0; strong scaling), "in_library" (N > 1 or --in-library: the same
+set through one hvs_create_multi context), "collective" (N > 1), "configs12" (BASELINE configs[1]/[2]: D = 10^6, Q = 10^4 on one
+GPU, resident and host -> host), "cpu_baseline" (the oracle's reference-faithful threaded engine timed on this host's cores over
+a bounded query sample, rank 0 at N = 1 only) and "recall_at_100" of the GPU answers against that oracle sample.
 """
 import argparse
 import importlib
