@@ -499,15 +499,19 @@ def main():
     if a.in_library or world > 1:
         # (host-side rendezvous through the process group's store: a collective barrier would leave a spinning RCCL kernel on
         # every GPU the in-library context is about to use)
-        store = dist.distributed_c10d._get_default_store() if use_dist else None
+        store = None
         if use_dist:
             torch.cuda.synchronize()
-            store.add("hvs_inlib_arrived", 1)
-            if rank == 0:
-                import datetime
-                t_wait = time.time()
-                while int(store.add("hvs_inlib_arrived", 0)) < world and time.time() - t_wait < 300:
-                    time.sleep(0.05)
+            try:
+                store = dist.distributed_c10d._get_default_store()
+                store.add("hvs_inlib_arrived", 1)
+                if rank == 0:
+                    t_wait = time.time()
+                    while int(store.add("hvs_inlib_arrived", 0)) < world and time.time() - t_wait < 300:
+                        time.sleep(0.05)
+            except Exception:                                            # no store API: a collective barrier on both sides instead
+                store = None
+                dist.barrier()
         if rank == 0:
             try:
                 QSET = 4_000_000
@@ -537,7 +541,9 @@ def main():
                 out["in_library"] = {"error": repr(ex)[:300]}
         if use_dist:
             import datetime
-            if rank == 0:
+            if store is None:
+                dist.barrier()
+            elif rank == 0:
                 store.set("hvs_inlib_done", "1")
             else:
                 store.wait(["hvs_inlib_done"], datetime.timedelta(seconds=900))

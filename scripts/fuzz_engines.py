@@ -1,7 +1,7 @@
 """Differential fuzzing on a GPU box: the filter engines (BF16, INT8, FP16 tiles) and HVS_ENGINE_AUTO must return the exact engine's bits (ids AND
 distances) for random data shapes, category counts, value ranges, special attribute values, query
 mixes and sample proportions.  Prints one line per case; exits 1 on the first mismatch."""
-import importlib, sys, time
+import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import hvs_testlib as T
@@ -39,6 +39,9 @@ def case(rng, i):
     k = min(k, n)
     if k < 8: k = 100
     parts = int(rng.choice([1, 1, 1, 2, 3]))                         # multi-GPU context with virtual ranks on GPU 0
+    rot = rng.choice(["", "0", "1", "1"])                            # INT8 tiles cut from rotated vectors: the planner's choice / never / always
+    if rot: os.environ["HVS_I8_ROTATE"] = str(rot)
+    else: os.environ.pop("HVS_I8_ROTATE", None)
     res = []
     for engine in (1, 2, 3, 4, 0):
         with (PKG.Engine(0) if parts == 1 else PKG.Engine(devices=[0] * parts)) as e:
@@ -46,7 +49,7 @@ def case(rng, i):
             ids, d = e.query(queries, sp); t = e.last_timing()
         res.append((ids, d, t.engine, t.fallback_queries, t.retry_queries))
     same = all(np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) for r in res[1:])
-    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} k={k} parts={parts} engines={','.join(str(r[2]) for r in res)} fallback={','.join(str(r[3]) for r in res[1:])} retried={','.join(str(r[4]) for r in res[1:])} -> {'ok' if same else 'MISMATCH'}", flush=True)
+    print(f"case {i}: n={n} nq={nq} ncat={ncat} profile={profile} scale={scale} sp={sp} k={k} parts={parts} rot={rot or '-'} engines={','.join(str(r[2]) for r in res)} fallback={','.join(str(r[3]) for r in res[1:])} retried={','.join(str(r[4]) for r in res[1:])} -> {'ok' if same else 'MISMATCH'}", flush=True)
     if not same:
         bad = np.nonzero(np.logical_or.reduce([(res[0][0] != r[0]).any(axis=1) for r in res[1:]]))[0]
         print("  first bad queries:", bad[:10], queries[bad[:3], :4]); np.savez("gpurun_out/fuzz_fail.npz", nodes=nodes, queries=queries, sp=sp)
