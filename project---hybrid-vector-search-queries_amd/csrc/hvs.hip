@@ -1750,10 +1750,19 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     if (filter_runs) {
         if ((rc = ensure_filter_workspace(c, std::min(nq, kBatchMfma)))) return rc;
         if ((rc = ensure_items(c))) return rc;
-        if (kLanes && nq > kBatchMfma && !c->lanes_failed) {  // calls of two batches and more alternate between two lanes
+        // calls of two batches and more alternate between two lanes: the spare lane's largest batch under either schedule (the
+        // resident API's full batches, hvs_query's ramped ones -- a call of 2 x 10^6 queries is ONE batch resident and three from
+        // host memory).  Without this the first such call allocated ~38 GB inside its own time (2.7 s on a 4 x 10^6-query call
+        // over two virtual ranks).
+        uint32_t spare_nq = 0;
+        for (int host = 0; host < 2; ++host) {
+            const std::vector<uint32_t> sched = batch_schedule(nq, kBatchMfma, host != 0);
+            for (size_t b = 1; b < sched.size(); b += 2) spare_nq = std::max(spare_nq, sched[b]);
+        }
+        if (kLanes && spare_nq && !c->lanes_failed) {
             LaneGuard lane{c, true};
             swap_lanes(c);
-            rc = ensure_filter_workspace(c, std::min(nq - kBatchMfma, kBatchMfma));
+            rc = ensure_filter_workspace(c, spare_nq);
             if (!rc) rc = ensure_items(c);
             if (rc == HVS_ENOMEM) {
                 (void)hipGetLastError();

@@ -1132,11 +1132,16 @@ def test_format_change_then_a_smaller_call_on_the_same_context(devices):
         assert np.all(buf_i[small:] == 0xDEADBEEF) and np.all(buf_d[small:] == -7.0), "a stale list of the earlier call was scattered past the result"
 
 
-def test_one_context_many_calls_fuzz():
+@pytest.mark.parametrize("rotate", ["", "1"], ids=["planner", "rotated_int8"])
+def test_one_context_many_calls_fuzz(rotate, monkeypatch):
     """per-context state survives between calls (tile format, guess tables keyed by k, candidate capacities, lists of
     re-run queries).  ONE context answers a sequence of calls with varying nq, k, sample_proportion, engine and API (host /
     resident), with a call far outside the data's box in the middle; every call is compared bit for bit with a fresh exact
     engine."""
+    if rotate:
+        monkeypatch.setenv("HVS_I8_ROTATE", rotate)   # (read per data set: INT8 tiles of this context are cut from rotated vectors)
+    else:
+        monkeypatch.delenv("HVS_I8_ROTATE", raising=False)
     n = 150_000
     rng = np.random.default_rng(20261005)
     nodes = T.gen_data(n, 91, T.GEN_V1, 10)
