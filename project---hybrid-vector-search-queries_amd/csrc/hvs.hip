@@ -1469,6 +1469,14 @@ std::vector<uint32_t> batch_schedule(uint32_t nq, uint32_t step, bool ramp_allow
     // two / three equal batches 183.3 / 189.0 ms, resident 169 ms)
     const uint32_t edge = kBatchMfma / 8u;
     const bool ramp = ramp_allowed && edge >= 1024u && nq >= 4u * edge;
+    // (A/B, HVS_SPLIT_SMALL=1: a small call as two half batches on the two lanes, ungated -- see run_queries)
+    static const bool kSplitSmall = env_u32("HVS_SPLIT_SMALL", 0u, 0u, 1u) != 0u;
+    if (kSplitSmall && step == kBatchMfma && nq >= 4096u && nq <= 65536u) {
+        const uint32_t half = hvs_ceil_div(hvs_ceil_div(nq, 2u), 512u) * 512u;
+        out.push_back(half);
+        out.push_back(nq - half);
+        return out;
+    }
     if (!ramp) {
         for (uint32_t off = 0; off < nq; off += step) out.push_back(std::min(step, nq - off));
         return out;
@@ -1563,7 +1571,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
         if (two_lanes) {
             // this batch's preparation starts behind the previous batch's (other lane) second-to-last filter launch, its seed
             // behind the last one; it records its own two events
-            const bool have_prev = b > 0 && c->lv.K >= 1u;
+            const bool have_prev = b > 0 && c->lv.K >= 1u && nq > 65536u;  // (small calls, HVS_SPLIT_SMALL: no gates)
             if (have_prev) HVS_HIP(c, hipStreamWaitEvent(c->stream, c->lv.K >= 2u ? c->ev_pdone[(b - 1u) & 1u] : c->ev_fdone[(b - 1u) & 1u], 0));
             c->gate_heavy = have_prev ? c->ev_fdone[(b - 1u) & 1u] : nullptr;
             c->ev_fdone_cur = c->ev_fdone[b & 1u];
@@ -1729,7 +1737,7 @@ int leaf_reserve(hvs_ctx* c, uint32_t nq)
     if (rc) return rc;
     // pinned staging of the host path (ids only: the distance slots follow the first call that asks for distances)
     if ((rc = ensure_staging(c, false, nq, nq))) return rc;
-    if (!c->dma_warm && c->h_out_ids[0] && c->h_in[0] && c->d_out_ids && c->d_q) {
+    if (!c->dma_warm && c->nq == 0u && c->h_out_ids[0] && c->h_in[0] && c->d_out_ids && c->d_q) {  // (no resident queries to overwrite)
         // the first DMA-sized copy in each direction sets up its engine queue (a cold 4 MB D2H took 6 ms): here, not in the first query
         const size_t bytes = std::min<size_t>((size_t)1 << 20, std::min((size_t)c->out_cap_q[0] * c->stage_k * sizeof(uint32_t),
                                                                       (size_t)c->in_cap_q[0] * HVS_QCOLS * sizeof(float)));
