@@ -205,14 +205,22 @@ struct HvsLdsRow2 {
 // flight.  (Left to the compiler the loop kept 2 reads in flight and waited for each: ~35 s_nop and 27 s_waitcnt per row.)
 // The arithmetic and its order per accumulator are hvs_exact_dist_pk's: acc2[k] takes dims (8b + 2k, 8b + 2k + 1) for
 // b = 0..11 in order, then the masked tail, then the hsum tree (optimized_impl.h:96-125, :37-47).
+// (ceiling experiments, never shipped: HVS_EXPERIMENT_EXACT=1 reads every other step's row data from LDS and re-uses the registers
+// for the steps between -- half the ds_read_b128 traffic, wrong distances; =2 drops the multiplications -- two thirds of the vector
+// arithmetic.  profiles/r04/exact_engine_ceiling.txt)
+#if defined(HVS_EXPERIMENT_EXACT) && HVS_EXPERIMENT_EXACT == 2
+#define HVS_LDS_SQ(t) t
+#else
+#define HVS_LDS_SQ(t) t * t
+#endif
 #define HVS_LDS_STEP(LO, HI, B)                                                                     \
     {                                                                                               \
         hvs_f2 t0 = hvs_f2{LO.x, LO.y} - q2[4 * (B) + 0], t1 = hvs_f2{LO.z, LO.w} - q2[4 * (B) + 1]; \
         hvs_f2 t2 = hvs_f2{HI.x, HI.y} - q2[4 * (B) + 2], t3 = hvs_f2{HI.z, HI.w} - q2[4 * (B) + 3]; \
-        t0 = t0 * t0;                                                                               \
-        t1 = t1 * t1;                                                                               \
-        t2 = t2 * t2;                                                                               \
-        t3 = t3 * t3;                                                                               \
+        t0 = HVS_LDS_SQ(t0);                                                                        \
+        t1 = HVS_LDS_SQ(t1);                                                                        \
+        t2 = HVS_LDS_SQ(t2);                                                                        \
+        t3 = HVS_LDS_SQ(t3);                                                                        \
         a0 = a0 + t0;                                                                               \
         a1 = a1 + t1;                                                                               \
         a2 = a2 + t2;                                                                               \
@@ -240,10 +248,15 @@ __device__ __forceinline__ float hvs_exact_dist_pk_lds(const float4* rowp, const
 #if HVS_LDS_RING3
     float4 A0 = rowp[0], A1 = rowp[1], B0 = rowp[2], B1 = rowp[3], C0 = rowp[4], C1 = rowp[5];
     __builtin_amdgcn_sched_barrier(0);
+#if defined(HVS_EXPERIMENT_EXACT) && HVS_EXPERIMENT_EXACT == 1
+#define HVS_LDS_REFILL(NEXT) ((NEXT) >= 0 && (((NEXT) / 2) & 1) == 0)
+#else
+#define HVS_LDS_REFILL(NEXT) ((NEXT) >= 0)
+#endif
 #define HVS_LDS_ONE(X0, X1, B, NEXT)                    \
     HVS_LDS_STEP(X0, X1, (B))                           \
     __builtin_amdgcn_sched_barrier(0);                  \
-    if ((NEXT) >= 0) {                                  \
+    if (HVS_LDS_REFILL(NEXT)) {                         \
         X0 = rowp[(NEXT) >= 0 ? (NEXT) : 0];            \
         if ((NEXT) + 1 < 25) X1 = rowp[(NEXT) >= 0 ? (NEXT) + 1 : 0]; \
     }                                                   \
