@@ -193,8 +193,6 @@ const uint32_t kRescoreBlocks = env_u32("HVS_RESCORE_BLOCKS", 0u, 0u, 64u);  // 
 const uint32_t kSeedWaves = env_u32("HVS_SEED_WAVES", 16384u, 64u, 1u << 20);
 // exact full scan: rows through LDS (1) or through the scalar cache (0); HVS_SCAN_LDS overrides for A/B runs
 const bool kScanRowsThroughLds = env_u32("HVS_SCAN_LDS", 1u, 0u, 1u) != 0u;
-// exact full scan with two lanes per query (hvs_k_scan_exact_lds2; HVS_SCAN_H2=0: one lane per query, A/B runs)
-const bool kScanTwoLanes = env_u32("HVS_SCAN_H2", 0u, 0u, 1u) != 0u;
 // INT8 tiles are built for v_mfma_i32_16x16x64_i8 (HVS_FMT_I8X16: 1.16x the pair rate of the 32x32x32 shape in the
 // filter loop, scripts/mfma_shape_lab.hip); HVS_I8_SHAPE=32 selects the 32x32x32 layout (HVS_FMT_I8) for A/B runs
 const int kI8Fmt = env_u32("HVS_I8_SHAPE", 16u, 16u, 32u) == 32u ? HVS_FMT_I8 : HVS_FMT_I8X16;
@@ -470,11 +468,7 @@ int run_batch_exact(hvs_ctx* c, uint32_t q0, uint32_t nqb, uint32_t sn, const ui
         const dim3 grid(p.nq_pad / 256u, p.nchunks);
         with_cap(c->cap, [&](auto CAPT) {
             constexpr int CAP = decltype(CAPT)::value;
-            if (kScanRowsThroughLds && kScanTwoLanes && !c->scalar_order) {
-                // two lanes per query: a workgroup serves 128 query slots (nq_pad is a multiple of 256)
-                hipLaunchKernelGGL((hvs_k_scan_exact_lds2<CAP>), dim3(p.nq_pad / 128u, p.nchunks), dim3(256), 0, c->stream, c->d_data, c->d_q, qorder,
-                                   nqb, p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);
-            } else if (kScanRowsThroughLds) {
+            if (kScanRowsThroughLds) {
                 if (c->scalar_order)
                     hipLaunchKernelGGL((hvs_k_scan_exact_lds<true, CAP>), grid, dim3(256), 0, c->stream, c->d_data, c->d_q, qorder, nqb,
                                        p.nq_pad, sn, p.rows_per_chunk, c->d_cand, c->d_cand_cnt, stat, c->k);

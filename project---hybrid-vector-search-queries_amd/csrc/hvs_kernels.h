@@ -445,195 +445,6 @@ __global__ __launch_bounds__(256, HVS_LDS_SCAN_WGS) void hvs_k_scan_exact_lds(
 }
 
 // ---------------------------------------------------------------------------------------------
-// hvs_k_scan_exact_lds2 -- the LDS-staged scan with TWO LANES PER QUERY (round 4).
-// hvs_k_scan_exact_lds is latency-bound at three waves per SIMD (profiles/r04/exact_engine_ceiling.txt): 100 of its 168
-// registers per lane hold the query, which leaves no room for a fourth wave.  Here lanes l and l + 32 share query l & 31:
-// the lower half-wave plays the reference's AVX lanes 0..3 (dims 8b .. 8b+3 of every 8-wide step, optimized_impl.h:110-117),
-// the upper half-wave lanes 4..7 (dims 8b+4 .. 8b+7 and the masked tail 96..99, :118-123) -- each accumulator still sums its
-// own dimensions in the reference's order; the horizontal sum (:37-47) needs the partner's two packed accumulators, which
-// cross the half-waves by two 64-bit swaps, and float addition is commutative, so both lanes end with the reference's bits.
-// 52 query registers per lane instead of 100: four to five waves per SIMD hide what three could not.  A wave serves 32
-// queries, a workgroup 128; candidate lists, admission (by the lower half-wave) and the list cut are hvs_k_scan_exact_lds's.
-// ---------------------------------------------------------------------------------------------
-#ifndef HVS_LDS2_WGS
-#define HVS_LDS2_WGS 4
-#endif
-__device__ __forceinline__ float hvs_exact_dist_pk_lds_h2(const float4* rowp, const hvs_f2* qh, uint32_t half)
-{
-    hvs_f2 a0 = hvs_f2{0.0f, 0.0f}, a1 = a0;
-    const float4* rp = rowp + half;  // this lane's float4 of step b: rowp[2 b + half]
-    float4 A = rp[0], B = rp[2], C = rp[4];
-    __builtin_amdgcn_sched_barrier(0);
-#define HVS_H2_STEP(X, Bs, NEXT)                                                          \
-    {                                                                                     \
-        hvs_f2 t0 = hvs_f2{X.x, X.y} - qh[2 * (Bs)], t1 = hvs_f2{X.z, X.w} - qh[2 * (Bs) + 1]; \
-        t0 = t0 * t0;                                                                     \
-        t1 = t1 * t1;                                                                     \
-        a0 = a0 + t0;                                                                     \
-        a1 = a1 + t1;                                                                     \
-    }                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    if ((NEXT) >= 0) X = (NEXT) == 24 ? rowp[24] : rp[(NEXT) >= 0 ? (NEXT) : 0];          \
-    __builtin_amdgcn_sched_barrier(0);
-    HVS_H2_STEP(A, 0, 6)
-    HVS_H2_STEP(B, 1, 8)
-    HVS_H2_STEP(C, 2, 10)
-    HVS_H2_STEP(A, 3, 12)
-    HVS_H2_STEP(B, 4, 14)
-    HVS_H2_STEP(C, 5, 16)
-    HVS_H2_STEP(A, 6, 18)
-    HVS_H2_STEP(B, 7, 20)
-    HVS_H2_STEP(C, 8, 22)
-    HVS_H2_STEP(A, 9, 24)   // A <- dims 96..99 (the masked tail, used by the upper half-wave)
-    HVS_H2_STEP(B, 10, -1)
-    HVS_H2_STEP(C, 11, -1)
-#undef HVS_H2_STEP
-    {
-        hvs_f2 t2 = hvs_f2{A.x, A.y} - qh[24];
-        hvs_f2 t3 = hvs_f2{A.z, A.w} - qh[25];
-        t2 = t2 * t2;
-        t3 = t3 * t3;
-        const hvs_f2 w0 = a0 + t2, w1 = a1 + t3;
-        a0 = half ? w0 : a0;  // accumulators 4..7 only (optimized_impl.h:118-123)
-        a1 = half ? w1 : a1;
-    }
-    // (a0, a1) of the lower half-wave = the reference's accumulators (0,1), (2,3); of the upper one (4,5), (6,7).
-    // v_permlane32_swap(x, x) leaves [x.lower, x.lower] and [x.upper, x.upper] in its two registers: their sum is
-    // acc_j + acc_{j+4} on BOTH lanes of the query, without the LDS round trip a ds_bpermute would put at the end of every row
-    auto pair_sum = [](float x) -> float {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lower + upper: the reference's acc_j + acc_{j+4} (f32 addition commutes)
-    };
-    const float s0 = pair_sum(a0.x), s1 = pair_sum(a0.y);  // acc0 + acc4, acc1 + acc5
-    const float s2 = pair_sum(a1.x), s3 = pair_sum(a1.y);  // acc2 + acc6, acc3 + acc7
-    const float a = s0 + s1;
-    const float b2 = s2 + s3;
-    return a + b2;
-}
-
-template <int CAP>
-__global__ __launch_bounds__(256, HVS_LDS2_WGS) void hvs_k_scan_exact_lds2(
-    const float* __restrict__ D, const float* __restrict__ Q, const uint32_t* __restrict__ qorder, uint32_t nq,
-    uint32_t nq_pad, uint32_t sn, uint32_t rows_per_chunk, uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-    unsigned long long* __restrict__ counters, uint32_t knn)
-{
-    __shared__ float4 srow[2][HVS_LDS_ROWS * HVS_LDS_ROW_F / 4];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t half = lane >> 5;
-    const uint32_t qwave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t slot = qwave * 32u + (lane & 31u);
-    const uint32_t chunk = blockIdx.y;
-    const bool wave_active = qwave * 32u < nq;  // inactive waves still help staging and meet the barriers
-
-    const bool have_q = slot < nq;
-    const uint32_t qi = qorder[have_q ? slot : (nq - 1u)];
-    const float* __restrict__ qrow = Q + (size_t)qi * HVS_QCOLS;
-    HvsQParams p = hvs_parse_query(qrow);
-    if (!have_q) p.type = 4u;
-    hvs_f2 qh[26];  // this lane's half of the query: (8b + 4 half .. + 3) for b = 0..11, then dims 96..99
-#pragma unroll
-    for (int b = 0; b < 12; ++b) {
-        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 8 * b + 4 * (int)half);
-        qh[2 * b] = hvs_f2{v4.x, v4.y};
-        qh[2 * b + 1] = hvs_f2{v4.z, v4.w};
-    }
-    {
-        const float4 v4 = *reinterpret_cast<const float4*>(qrow + 4 + 96);
-        qh[24] = hvs_f2{v4.x, v4.y};
-        qh[25] = hvs_f2{v4.z, v4.w};
-    }
-
-    const uint32_t r0 = chunk * rows_per_chunk;
-    uint32_t r1 = r0 + rows_per_chunk;
-    if (r1 > sn || r1 < r0) r1 = sn;
-    if (r0 >= r1) return;  // uniform over the workgroup
-
-    constexpr uint32_t kItems = HVS_LDS_ROWS * 26u;
-    float4 stg[(kItems + 255u) / 256u];
-    auto load_block = [&](uint32_t j0) {
-#pragma unroll
-        for (uint32_t k = 0; k < (kItems + 255u) / 256u; ++k) {
-            const uint32_t e = threadIdx.x + 256u * k;
-            const uint32_t r = e / 26u, c = e % 26u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < kItems && j0 + r < r1) {
-                const float* __restrict__ src = D + (size_t)(j0 + r) * HVS_DCOLS;
-                if (c < 25u) {
-                    const float2 a = *reinterpret_cast<const float2*>(src + 2 + 4 * c);
-                    const float2 b = *reinterpret_cast<const float2*>(src + 4 + 4 * c);
-                    v = make_float4(a.x, a.y, b.x, b.y);
-                } else {
-                    const float2 a = *reinterpret_cast<const float2*>(src);
-                    v = make_float4(a.x, a.y, 0.f, 0.f);
-                }
-            }
-            stg[k] = v;
-        }
-    };
-    auto store_block = [&](uint32_t buf) {
-#pragma unroll
-        for (uint32_t k = 0; k < (kItems + 255u) / 256u; ++k) {
-            const uint32_t e = threadIdx.x + 256u * k;
-            if (e < kItems) srow[buf][(e / 26u) * (HVS_LDS_ROW_F / 4) + (e % 26u)] = stg[k];
-        }
-    };
-
-    uint64_t* __restrict__ mylist = cand + ((size_t)chunk * nq_pad + slot) * CAP;
-    float tau = __builtin_nanf("");  // (see hvs_k_scan_exact)
-    uint32_t cnt = 0;
-    uint32_t npass = 0, nscan = 0;
-
-    load_block(r0);
-    store_block(0u);
-    __syncthreads();
-    uint32_t buf = 0;
-    for (uint32_t j0 = r0; j0 < r1; j0 += HVS_LDS_ROWS) {
-        const bool more = j0 + HVS_LDS_ROWS < r1;
-        if (more) load_block(j0 + HVS_LDS_ROWS);
-        if (wave_active) {
-            const uint32_t nrow = (r1 - j0) < HVS_LDS_ROWS ? (r1 - j0) : HVS_LDS_ROWS;
-            for (uint32_t r = 0; r < nrow; ++r) {
-                const float4* rowp = &srow[buf][r * (HVS_LDS_ROW_F / 4)];
-                const float4 attr = rowp[25];
-                const bool pass = hvs_row_passes(p, attr.x, attr.y);
-                const uint64_t pmask = __ballot(pass) & 0xFFFFFFFFull;  // (both lanes of a query say the same)
-                if (pmask == 0ull) continue;
-                npass += (uint32_t)__popcll(pmask);
-                nscan += 32u;
-                const float dist = hvs_exact_dist_pk_lds_h2(rowp, qh, half);
-                if (half == 0u && pass && !(dist >= tau)) {
-                    mylist[cnt] = hvs_make_key(dist, j0 + r);
-                    ++cnt;
-                }
-                uint64_t full = __ballot(half == 0u && cnt == (uint32_t)CAP);
-                if (full != 0ull) {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    while (full != 0ull) {
-                        const uint32_t l = (uint32_t)__builtin_ctzll(full);
-                        full &= full - 1ull;
-                        uint64_t* lst = cand + ((size_t)chunk * nq_pad + (qwave * 32u + l)) * CAP;
-                        const uint64_t kth = hvs_wave_select_prune<CAP / 64>(lst, (uint32_t)CAP, knn, lane);
-                        if (lane == l) {
-                            cnt = knn;
-                            tau = hvs_key_dist(kth);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                }
-            }
-        }
-        if (more) store_block(buf ^ 1u);
-        __syncthreads();
-        buf ^= 1u;
-    }
-    if (have_q && half == 0u) cand_cnt[(size_t)chunk * nq_pad + slot] = cnt;
-    if (wave_active && lane == 0u) {
-        atomicAdd(&counters[0], (unsigned long long)npass);
-        atomicAdd(&counters[1], (unsigned long long)nscan);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // hvs_k_select -- per query: merge the per-chunk candidate lists (the counterpart of
 // Knn::merge, optimized_impl.h:337-385 + optimized_parallel.hpp:142-146), pad with the last
 // rows of D when fewer than 100 rows matched (optimized_parallel.hpp:149-157: rows n-1, n-2,
