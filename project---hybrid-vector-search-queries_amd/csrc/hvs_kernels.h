@@ -385,6 +385,10 @@ __global__ __launch_bounds__(256, HVS_LDS_SCAN_WGS) void hvs_k_scan_exact_lds(
     float tau = __builtin_nanf("");  // (see hvs_k_scan_exact)
     uint32_t cnt = 0;
     uint32_t npass = 0, nscan = 0;
+    // queries are sorted by type: a wave of type-0 queries only (the exact engine's slowest class) skips the per-row predicate --
+    // one LDS read with its wait at the head of every row, three compares and eight scalar mask operations
+    const bool wave_all0 = __ballot(have_q && p.type != 0u) == 0ull;
+    const uint32_t nhave = (uint32_t)__popcll(__ballot(have_q));
 
     load_block(r0);
     store_block(0u);
@@ -397,11 +401,17 @@ __global__ __launch_bounds__(256, HVS_LDS_SCAN_WGS) void hvs_k_scan_exact_lds(
             const uint32_t nrow = (r1 - j0) < HVS_LDS_ROWS ? (r1 - j0) : HVS_LDS_ROWS;
             for (uint32_t r = 0; r < nrow; ++r) {
                 const float4* rowp = &srow[buf][r * (HVS_LDS_ROW_F / 4)];
-                const float4 attr = rowp[25];
-                const bool pass = hvs_row_passes(p, attr.x, attr.y);
-                const uint64_t pmask = __ballot(pass);
-                if (pmask == 0ull) continue;
-                npass += (uint32_t)__popcll(pmask);
+                bool pass;
+                if (wave_all0) {  // (wave-uniform) a wave of pure k-NN queries takes every row: no attribute read, no predicate
+                    pass = have_q;
+                    npass += nhave;
+                } else {
+                    const float4 attr = rowp[25];
+                    pass = hvs_row_passes(p, attr.x, attr.y);
+                    const uint64_t pmask = __ballot(pass);
+                    if (pmask == 0ull) continue;
+                    npass += (uint32_t)__popcll(pmask);
+                }
                 nscan += 64u;
                 float dist;
                 if (SCALAR_ORDER) {
