@@ -1552,7 +1552,9 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
             swap_lanes(c);
             lane.on = true;
             // the spare workspace is allocated here, ahead of the batch: without room for it the call stays on one lane
-            int rcw = ensure_filter_workspace(c, nqb);
+            // (HVS_TEST_NO_SPARE=1: tests take the out-of-memory path without filling 288 GB)
+            static const bool kTestNoSpare = env_u32("HVS_TEST_NO_SPARE", 0u, 0u, 1u) != 0u;
+            int rcw = kTestNoSpare ? HVS_ENOMEM : ensure_filter_workspace(c, nqb);
             if (!rcw) rcw = ensure_items(c);
             if (rcw == HVS_ENOMEM) {
                 (void)hipGetLastError();

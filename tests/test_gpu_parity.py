@@ -1223,3 +1223,47 @@ def test_rotated_int8_tiles_parity(profile):
         assert pairs["1"] < 0.7 * pairs["0"], pairs
     ref, _ = T.oracle_query(nodes, queries[:48], threads=8)
     T.check_parity(nodes, queries[:48], want_i[:48], ref, got_dists=want_d[:48])
+
+
+_LANES_CODE = r"""
+import importlib, os, sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import hvs_testlib as T
+PKG = importlib.import_module('project---hybrid-vector-search-queries_amd')
+n, nq = 300_000, 40_000                     # HVS_MFMA_BATCH=4096: calls of 10 batches, alternating between the two lanes
+nodes = T.gen_data(n, 61, T.GEN_V1, 10); queries = T.gen_queries(nq, 62, T.GEN_V1, 10)
+with PKG.Engine(0) as x:
+    x.set_engine(PKG.ENGINE_EXACT_SCAN); x.load_data(nodes)
+    want_i, want_d = x.query(queries, 1.0)
+for engine in (PKG.ENGINE_AUTO, PKG.ENGINE_MFMA_I8, PKG.ENGINE_MFMA_F16, PKG.ENGINE_MFMA_FILTER):
+    with PKG.Engine(0) as e:
+        e.set_engine(engine); e.load_data(nodes)
+        for rep in range(2):                # the second call finds both lanes' workspaces (or the fallback decision) in place
+            ids, d = e.query(queries, 1.0)
+            t = e.last_timing()
+            assert np.array_equal(ids, want_i) and np.array_equal(d.view(np.uint32), want_d.view(np.uint32)), (engine, rep)
+        e.upload_queries(queries); e.query_resident(1000, 30_000, 1.0); e.sync()
+        ri, rd = e.download_results(1000, 30_000)
+        assert np.array_equal(ri, want_i[1000:31000]) and np.array_equal(rd.view(np.uint32), want_d[1000:31000].view(np.uint32)), engine
+        print('engine', engine, 'ran', t.engine, 'launches', t.main_kernel_launches, 'retried', t.retry_queries)
+ref, _ = T.oracle_query(nodes, queries[:64]); T.check_parity(nodes, queries[:64], want_i[:64], ref, got_dists=want_d[:64])
+print('SUBPROCESS-OK')
+"""
+
+
+@pytest.mark.parametrize("mode", ["two_lanes", "one_lane", "no_room_for_the_spare_lane"])
+def test_calls_of_many_batches_on_two_lanes(mode):
+    """Round 4: consecutive batches of a call run on two lanes (stream + workspace each, gated behind each other's last filter
+    launches; csrc/hvs.hip HvsLane).  Small batches (HVS_MFMA_BATCH=4096) make every call ten batches long: host path twice,
+    resident path on an inner range, all filter engines, bit-equal to the exact engine -- with both lanes, with HVS_LANES=0, and
+    when the spare lane's workspace cannot be allocated (HVS_TEST_NO_SPARE=1: the call must continue on one lane, silently)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HVS_MFMA_BATCH="4096")
+    if mode == "one_lane":
+        env["HVS_LANES"] = "0"
+    if mode == "no_room_for_the_spare_lane":
+        env["HVS_TEST_NO_SPARE"] = "1"
+    r = subprocess.run([sys.executable, "-c", _LANES_CODE], capture_output=True, text=True, env=env, cwd=T.REPO)
+    print(r.stdout[-800:])
+    assert "SUBPROCESS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
