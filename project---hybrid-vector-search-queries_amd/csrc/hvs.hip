@@ -1544,6 +1544,15 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     // spare lane starts behind the call's counter resets (ev_q0) and the main stream joins it before the call ends.
     bool two_lanes = mfma && kLanes && sched.size() >= 2 && !c->lanes_failed;
     bool spare_used = false;
+    struct JoinOnError {  // a call that fails half-way leaves no kernels running on the spare lane behind the caller's back
+        hvs_ctx* c;
+        const bool* used;
+        bool ok = false;
+        ~JoinOnError()
+        {
+            if (!ok && *used && c->spare.stream) (void)hipStreamSynchronize(c->spare.stream);
+        }
+    } join_on_error{c, &spare_used};
     uint32_t off = 0;
     for (size_t b = 0; b < sched.size(); ++b) {
         const uint32_t nqb = sched[b];
@@ -1604,6 +1613,7 @@ int run_queries(hvs_ctx* c, uint32_t q0, uint32_t nq, float sample_proportion, H
     c->timing.n_gpus = 1;
     c->timing.flags = (c->index_too_large ? HVS_TIMING_INDEX_TOO_LARGE : 0u) | (mfma && HVS_IS_I8(c->tile_fmt) && c->i8_rot_built ? HVS_TIMING_I8_ROTATED : 0u);
     c->timing_valid = true;
+    join_on_error.ok = true;
     return HVS_OK;
 }
 
