@@ -173,3 +173,14 @@ def test_host_planning_rules_guess_order_statistic_and_batch_schedule():
         for host in (0, 1):
             sc = sched(nq, host)
             assert sum(sc) == nq and all(0 < b <= big for b in sc), (nq, host, sc)
+
+
+def test_bench_command_line_parses_without_a_gpu():
+    """bench.py's contract flags and the round-4 legs (`--in-library`, `--only-configs12`, `--per-step-calls`) are known to its parser;
+    nothing GPU-side is touched by --help."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(T.REPO, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    for flag in ("--gpus", "--steps", "--warmup", "--in-library", "--in-library-only", "--only-configs12", "--per-step-calls", "--force-dist"):
+        assert flag in r.stdout, flag
