@@ -2395,7 +2395,7 @@ int for_each_resident_part(hvs_ctx* root, uint32_t q0, uint32_t nq, Fn fn)
 
 extern "C" {
 
-const char* hvs_version(void) { return "hvs-mi355x 0.3 (gfx950)"; }
+const char* hvs_version(void) { return "hvs-mi355x 0.4 (gfx950)"; }
 
 uint32_t hvs_plan_guess_m(uint32_t k, double seen_fraction, uint32_t pfail)
 {
