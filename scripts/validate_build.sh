@@ -1,7 +1,8 @@
 #!/bin/bash
+# GPU suite + smoke + the default bench with the driver's flags on a GPU box: gpurun -- bash scripts/validate_build.sh
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r04_final
+OUT=$ROOT/gpurun_out/validate
 mkdir -p $OUT
 cd $ROOT
 timeout -k 10 850 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1 || { tail -60 $OUT/tests_gpu.log; exit 1; }
