@@ -1267,3 +1267,32 @@ def test_calls_of_many_batches_on_two_lanes(mode):
     r = subprocess.run([sys.executable, "-c", _LANES_CODE], capture_output=True, text=True, env=env, cwd=T.REPO)
     print(r.stdout[-800:])
     assert "SUBPROCESS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_planner_picks_rotated_int8_tiles_for_pca_like_data_at_d1e7():
+    """Round 4, the planner end to end at full size: D = 10^7 PCA-like rows (include/hvs_gen.h HVS_GEN_PCA) under HVS_ENGINE_AUTO.  The
+    probe finds the plain INT8 band too wide (every probe query overflows its lists), tries the rotated INT8 tiles and the FP16 tiles
+    and keeps the rotated ones (hvs_timing.flags & 4); 2^18 mixed queries (1 % outside the data's box) run without exact-engine
+    fallbacks beyond a handful, and a sample is bit-equal to the exact engine and confirmed by the oracle."""
+    n, nq = 10_000_000, 1 << 18
+    with PKG.Engine(0) as e:
+        e.gen_data(n, T.SEED_DATA, T.GEN_PCA, 100)
+        e.gen_queries(nq, T.SEED_QUERY, T.GEN_PCA, 100, -1, 0)
+        queries = e.download_queries(0, nq)
+        e.query_resident(0, nq, 1.0)
+        e.sync()
+        t = e.last_timing()
+        ids, dists = e.download_results(0, nq)
+        print("PCA-like D=1e7: engine", t.engine, "flags", t.flags, "device ms %.0f" % t.query_ms, "rescored/query %.0f" % (t.rescored_pairs / nq),
+              "retried", t.retry_queries, "exact", t.fallback_queries)
+        assert t.engine == PKG.ENGINE_MFMA_I8 and (t.flags & 4), t.as_dict()
+        assert t.fallback_queries <= nq // 1000
+        assert np.all(np.diff(dists, axis=1) >= 0) and ids.max() < n
+        sel = np.arange(0, nq, nq // 512)[:512]
+        e.set_engine(PKG.ENGINE_EXACT_SCAN)
+        ids_x, d_x = e.query(queries[sel], 1.0)
+        assert np.array_equal(ids[sel], ids_x) and np.array_equal(dists[sel].view(np.uint32), d_x.view(np.uint32))
+        nodes = e.download_data(0, n)
+    pick = sel[:32]
+    ref, _ = T.oracle_query(nodes, queries[pick], threads=16)
+    T.check_parity(nodes, queries[pick], ids[pick], ref, got_dists=dists[pick])
